@@ -1,0 +1,243 @@
+// csrc/geometry.hpp -- per-point / per-voxel arithmetic of the fusion path, host+device.
+//
+// Every function states the reference expression it must agree with bit-for-bit
+// (grid.hpp = .../include/utilities/OccupancyGrid.hpp, node.cpp = .../src/pointcloud_fusion_and_filter.cpp).
+// The translation unit is compiled with -ffp-contract=off: the reference build has no -march flag
+// (CMakeLists.txt:5), i.e. x86-64 SSE2 without FMA, so no product-sum may be fused here either.
+// f32/f64 divide and sqrt are the correctly rounded forms (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt; never build this file with -ffast-math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "det_math.hpp"
+
+namespace hfpf {
+
+struct F3 {
+    float x, y, z;
+};
+
+// Grid constants, passed by value to every kernel (lives in SGPRs / kernarg).
+struct GridParams {
+    double min[3];  // xmin_,ymin_,zmin_   grid.hpp:104
+    double max[3];  // xmax_,ymax_,zmax_
+    double res;     // xres_ = (double)(float)resolution  grid.hpp:614-619 (all three axes equal, node.cpp:161)
+    int32_t dim[3];   // xdim_,ydim_,zdim_ truncated  grid.hpp:623-625
+    int32_t bdim[3];  // bricks per axis covering the (dim+1) storage extent  grid.hpp:626
+    double zclip_min, zclip_max;  // node.cpp:92-93
+    double cyl_r;                 // grid.hpp:36
+    float ball_r;                 // (float)kBballRadius, grid.hpp:35,42
+    int32_t K;                    // node.cpp:311
+    int32_t gate;                 // grid.hpp:352
+    // fixed-point scales (powers of two) of the order-free statistic sums, see stats.hpp
+    double s1_scale, s2_scale, sd_scale, sdd_scale;
+};
+
+HFPF_HD float sum3(float a, float b, float c) { return a + (b + c); }  // Eigen fixed-size-3 redux: c0 + (c1 + c2)
+HFPF_HD float dot3(F3 a, F3 b) { return sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
+HFPF_HD F3 sub3(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+HFPF_HD F3 add3(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+HFPF_HD F3 mul3(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
+HFPF_HD F3 div3(F3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+
+// `int v = floor(double)` as the reference's x86 build performs it (cvttsd2si: NaN / overflow -> INT_MIN).
+HFPF_HD int32_t to_int_x86(double v)
+{
+    if (!(v == v) || v >= 2147483648.0 || v < -2147483648.0) return INT_MIN;
+    return (int32_t)v;
+}
+
+// node.cpp:289 pcl::transformPointCloud<PointXYZRGB,double>: f64 products summed left to right, one rounding to f32.
+HFPF_HD F3 transform_point(const double* T, float x, float y, float z)
+{
+    const double dx = (double)x, dy = (double)y, dz = (double)z;
+    F3 q;
+    q.x = (float)(((T[0] * dx + T[1] * dy) + T[2] * dz) + T[3]);
+    q.y = (float)(((T[4] * dx + T[5] * dy) + T[6] * dz) + T[7]);
+    q.z = (float)(((T[8] * dx + T[9] * dy) + T[10] * dz) + T[11]);
+    return q;
+}
+
+// node.cpp:251-255 z-clip in the camera frame: strict on both sides, NaN rejected.
+HFPF_HD bool zclip_pass(const GridParams& g, float z) { return ((double)z < g.zclip_max) && ((double)z > g.zclip_min); }
+
+// grid.hpp:639-645 validPoints: float promoted to double in each compare; strict interior.
+HFPF_HD bool valid_point(const GridParams& g, F3 p)
+{
+    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    return !(x >= g.max[0] || y >= g.max[1] || z >= g.max[2] || x <= g.min[0] || y <= g.min[1] || z <= g.min[2]);
+}
+
+// grid.hpp:630-637 getVoxelCoords(Vector3f): floor((double(p) - min) / res) truncated to int.
+HFPF_HD void voxel_coords(const GridParams& g, F3 p, int32_t& ix, int32_t& iy, int32_t& iz)
+{
+    ix = to_int_x86(floor(((double)p.x - g.min[0]) / g.res));
+    iy = to_int_x86(floor(((double)p.y - g.min[1]) / g.res));
+    iz = to_int_x86(floor(((double)p.z - g.min[2]) / g.res));
+}
+
+// grid.hpp:647-650 validCoord: cells with index == dim exist in storage but are never scanned.
+HFPF_HD bool valid_coord(const GridParams& g, int32_t x, int32_t y, int32_t z)
+{
+    return x >= 0 && y >= 0 && z >= 0 && x < g.dim[0] && y < g.dim[1] && z < g.dim[2];
+}
+
+// grid.hpp:131-135 getVoxelCenter: f64 `min + res*i + res/2.0`, narrowed to f32.
+HFPF_HD F3 voxel_center(const GridParams& g, int32_t x, int32_t y, int32_t z)
+{
+    const double h = g.res / 2.0;
+    F3 c;
+    c.x = (float)((g.min[0] + g.res * (double)x) + h);
+    c.y = (float)((g.min[1] + g.res * (double)y) + h);
+    c.z = (float)((g.min[2] + g.res * (double)z) + h);
+    return c;
+}
+
+// grid.hpp:40-49 projectPointToVector + grid.hpp:261-262 (norm widened to double, compared with
+// kCylinderRadius).  Returns membership; proj and dist are outputs.
+HFPF_HD bool cylinder_member(const GridParams& g, F3 pt, F3 centre, F3 n, F3& proj, double& dist)
+{
+    const F3 d_xyz = mul3(g.ball_r, n);
+    const F3 a = sub3(centre, d_xyz);
+    const F3 b = add3(centre, d_xyz);
+    const F3 ap = sub3(a, pt);
+    const F3 ab = sub3(a, b);
+    const float s = dot3(ap, ab) / dot3(ab, ab);
+    proj = sub3(a, mul3(s, ab));
+    const F3 df = sub3(pt, proj);
+    dist = (double)sqrtf(dot3(df, df));
+    return dist < g.cyl_r;
+}
+
+// ---- plane fit: pcl::computeMeanAndCovarianceMatrix + pcl::eigen33 (call sites grid.hpp:302,289) ----
+
+HFPF_HD void swapf(float& a, float& b)
+{
+    const float t = a;
+    a = b;
+    b = t;
+}
+
+// pcl::computeRoots2 (the literal 4.0 is a double in PCL: the discriminant is formed in f64).
+HFPF_HD void compute_roots2(float b, float c, float* roots)
+{
+    roots[0] = 0.0f;
+    float d = (float)((double)(b * b) - 4.0 * (double)c);
+    if ((double)d < 0.0) d = 0.0f;
+    const float sd = sqrtf(d);
+    roots[2] = 0.5f * (b + sd);
+    roots[1] = 0.5f * (b - sd);
+}
+
+// pcl::computeRoots for a symmetric 3x3 (m00,m01,m02,m11,m12,m22).
+HFPF_HD void compute_roots(float m00, float m01, float m02, float m11, float m12, float m22, float* roots)
+{
+    const float c0 = m00 * m11 * m22 + 2.0f * m01 * m02 * m12 - m00 * m12 * m12 - m11 * m02 * m02 - m22 * m01 * m01;
+    const float c1 = m00 * m11 - m01 * m01 + m00 * m22 - m02 * m02 + m11 * m22 - m12 * m12;
+    const float c2 = m00 + m11 + m22;
+    if (fabsf(c0) < FLT_EPSILON) {
+        compute_roots2(c2, c1, roots);
+        return;
+    }
+    const float s_inv3 = (float)(1.0 / 3.0);
+    const float s_sqrt3 = 1.7320508075688772f;  // sqrtf(3.0f) = 0x3FDDB3D7
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    const float rho = sqrtf(-a_over_3);
+    const float theta = det_atan2f(sqrtf(-q), half_b) * s_inv3;
+    const float cos_theta = det_cosf(theta);
+    const float sin_theta = det_sinf(theta);
+    roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    if (roots[0] >= roots[1]) swapf(roots[0], roots[1]);
+    if (roots[1] >= roots[2]) {
+        swapf(roots[1], roots[2]);
+        if (roots[0] >= roots[1]) swapf(roots[0], roots[1]);
+    }
+    if (roots[0] <= 0.0f) compute_roots2(c2, c1, roots);
+}
+
+HFPF_HD F3 cross3(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// pcl::eigen33(mat, eigenvalue, eigenvector): unit eigenvector of the smallest eigenvalue of the
+// symmetric matrix (c00,c01,c02,c11,c12,c22).
+HFPF_HD F3 eigen33_smallest(float c00, float c01, float c02, float c11, float c12, float c22)
+{
+    float scale = fmaxf(fmaxf(fmaxf(fabsf(c00), fabsf(c01)), fmaxf(fabsf(c02), fabsf(c11))), fmaxf(fabsf(c12), fabsf(c22)));
+    if (scale <= FLT_MIN) scale = 1.0f;
+    float s00 = c00 / scale, s01 = c01 / scale, s02 = c02 / scale, s11 = c11 / scale, s12 = c12 / scale, s22 = c22 / scale;
+    float ev[3];
+    compute_roots(s00, s01, s02, s11, s12, s22, ev);
+    s00 -= ev[0];
+    s11 -= ev[0];
+    s22 -= ev[0];
+    const F3 r0 = {s00, s01, s02}, r1 = {s01, s11, s12}, r2 = {s02, s12, s22};
+    const F3 v1 = cross3(r0, r1), v2 = cross3(r0, r2), v3 = cross3(r1, r2);
+    const float l1 = dot3(v1, v1), l2 = dot3(v2, v2), l3 = dot3(v3, v3);
+    if (l1 >= l2 && l1 >= l3) return div3(v1, sqrtf(l1));
+    if (l2 >= l1 && l2 >= l3) return div3(v2, sqrtf(l2));
+    return div3(v3, sqrtf(l3));
+}
+
+// Running single-pass f32 moments in neighbour-table order (pcl::computeMeanAndCovarianceMatrix, dense branch).
+struct Moments {
+    float a[9];
+    HFPF_HD void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < 9; i++) a[i] = 0.0f;
+    }
+    HFPF_HD void add(F3 p)
+    {
+        a[0] += p.x * p.x;
+        a[1] += p.x * p.y;
+        a[2] += p.x * p.z;
+        a[3] += p.y * p.y;
+        a[4] += p.y * p.z;
+        a[5] += p.z * p.z;
+        a[6] += p.x;
+        a[7] += p.y;
+        a[8] += p.z;
+    }
+    HFPF_HD F3 normal(int n) const
+    {
+        const float fn = (float)n;
+        float m[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) m[i] = a[i] / fn;
+        const float c00 = m[0] - m[6] * m[6];
+        const float c01 = m[1] - m[6] * m[7];
+        const float c02 = m[2] - m[6] * m[8];
+        const float c11 = m[3] - m[7] * m[7];
+        const float c12 = m[4] - m[7] * m[8];
+        const float c22 = m[5] - m[8] * m[8];
+        return eigen33_smallest(c00, c01, c02, c11, c12, c22);
+    }
+};
+
+// grid.hpp:393-396: flip the normal toward the viewpoint latched at first occupancy.
+HFPF_HD F3 orient_normal(F3 normal, F3 vp, F3 centre)
+{
+    F3 dir = sub3(vp, centre);
+    const float z = dot3(dir, dir);
+    if (z > 0.0f) dir = div3(dir, sqrtf(z));  // Eigen 3.3 normalized()
+    if (dot3(dir, normal) < 0.0f) normal = {normal.x * -1.0f, normal.y * -1.0f, normal.z * -1.0f};
+    return normal;
+}
+
+// grid.hpp:405: centre + (float)(i*xres_) * normal
+HFPF_HD F3 line_step(const GridParams& g, F3 centre, F3 normal, int i)
+{
+    const float step = (float)((double)i * g.res);
+    return add3(centre, mul3(step, normal));
+}
+
+}  // namespace hfpf

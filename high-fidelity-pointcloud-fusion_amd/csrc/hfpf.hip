@@ -1,0 +1,929 @@
+// csrc/hfpf.hip -- host side of libhfpf.so: handle, HBM pools, kernel orchestration, C ABI (include/hfpf.h).
+//
+// One HIP stream per handle; every entry point enqueues on it.  clean/extract are the only calls
+// that read device counters back (they are synchronisation points in the reference too: clean holds
+// grid_mtx_, node.cpp:305-321).  No CPU fallback exists: without a usable HIP device hfpf_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hfpf.h"
+#include "../../include/hfpf_probe.h"
+#include "kernels.hpp"
+
+using namespace hfpf;
+
+static_assert(sizeof(hfpf_row) == sizeof(Row), "hfpf_row layout");
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct StageSlot {  // pose / frame-id staging for one in-flight integrate call
+    double* h_pose = nullptr;
+    uint32_t* h_ids = nullptr;
+    double* d_pose = nullptr;
+    uint32_t* d_ids = nullptr;
+    uint32_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+struct FrameSlot {  // host-frame staging (pinned + device)
+    void* h = nullptr;
+    void* d = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+constexpr int kStageSlots = 8;
+constexpr int kFrameSlots = 2;
+
+}  // namespace
+
+struct hfpf_handle {
+    std::mutex mtx;
+    hfpf_config cfg;
+    GridParams g;
+    Tables t;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> allocs;
+    uint64_t device_bytes = 0;
+    size_t dir_entries = 0;
+    uint64_t n_slots = 0;
+    uint64_t max_touched = 0;
+
+    // host mirrors
+    bool dirty = false;
+    uint64_t n_linked = 0;  // log entries already chained
+    uint64_t frames_integrated = 0;
+    uint64_t clean_passes = 0;
+    uint32_t next_frame_id = 0;
+
+    StageSlot stage[kStageSlots];
+    int stage_next = 0;
+    FrameSlot fslot[kFrameSlots];
+    int fslot_next = 0;
+
+    // scratch
+    DevBuf sort_tmp, keys_a, keys_b, vals_a, vals_b, rows_dev, probe_a, probe_b, probe_c, probe_d, probe_e, probe_f;
+    unsigned long long* h_ctr = nullptr;  // pinned mirror of the counters
+
+    // kernel timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    std::vector<hipEvent_t> ev_free;
+    double t_integrate_ms = 0;
+    uint64_t n_integrate_launches = 0;
+};
+
+namespace {
+
+int fail(hfpf_handle* h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) return fail(h, HFPF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(hfpf_handle* h, T** out, uint64_t count, int memset_byte = 0, bool do_memset = true)
+{
+    void* p = nullptr;
+    const size_t bytes = std::max<uint64_t>(count, 1) * sizeof(T);
+    HIPCHK(h, hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    h->device_bytes += bytes;
+    if (do_memset) HIPCHK(h, hipMemsetAsync(p, memset_byte, bytes, h->stream));
+    *out = (T*)p;
+    return HFPF_OK;
+}
+
+int scratch(hfpf_handle* h, DevBuf& b, size_t bytes)
+{
+    if (b.bytes >= bytes && b.p) return HFPF_OK;
+    if (b.p) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(b.p));
+        h->device_bytes -= b.bytes;
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    HIPCHK(h, hipMalloc(&b.p, want));
+    b.bytes = want;
+    h->device_bytes += want;
+    return HFPF_OK;
+}
+
+inline unsigned blocks_for(uint64_t n, unsigned bs) { return (unsigned)std::max<uint64_t>(1, (n + bs - 1) / bs); }
+
+__global__ void k_set_ctr(unsigned long long* ctr, int idx, unsigned long long v) { ctr[idx] = v; }
+
+int read_counters(hfpf_handle* h)
+{
+    HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->t.ctr, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HFPF_OK;
+}
+
+int check_device_errors(hfpf_handle* h)
+{
+    const unsigned long long e = h->h_ctr[C_ERR];
+    if (!e) return HFPF_OK;
+    std::string what;
+    if (e & E_BRICKS) what += " brick pool (max_bricks)";
+    if (e & E_LOG) what += " point log (max_log_points)";
+    if (e & E_OCC) what += " occupied list (max_normals*4)";
+    if (e & E_NORMALS) what += " normal records (max_normals)";
+    if (e & E_REG) what += " registrations (max_normals*7)";
+    if (e & E_DEP) what += " dependant table";
+    if (e & E_SPIN) what += " brick-claim spin bound";
+    if (e & E_DEPCNT) what += " >65535 dependants on one cell";
+    if (e & E_FRAME) what += " frame id >= max_frames";
+    return fail(h, HFPF_ERR_CAPACITY, "device pool overflow:%s", what.c_str());
+}
+
+int pow2_exponent_for(double bound) { return 38 - (int)std::ceil(std::log2(bound)); }
+
+int setup_params(hfpf_handle* h)
+{
+    const hfpf_config& c = h->cfg;
+    GridParams& g = h->g;
+    if (!(c.resolution > 0.f)) return fail(h, HFPF_ERR_BAD_CONFIG, "resolution must be > 0");
+    for (int a = 0; a < 3; a++)
+        if (!(c.bbox[2 * a + 1] > c.bbox[2 * a])) return fail(h, HFPF_ERR_BAD_CONFIG, "bounding_box axis %d: max <= min", a);
+    if (c.k != 2) return fail(h, HFPF_ERR_BAD_CONFIG, "k must be 2 (the reference probes exactly 125 neighbours, OccupancyGrid.hpp:334)");
+    if (c.K < 0 || c.K > 16) return fail(h, HFPF_ERR_BAD_CONFIG, "K out of range [0,16]");
+    if (!(c.cylinder_radius > 0) || !(c.ball_radius > 0)) return fail(h, HFPF_ERR_BAD_CONFIG, "radii must be > 0");
+    g.res = (double)c.resolution;  // float -> double, grid.hpp:614-619
+    for (int a = 0; a < 3; a++) {
+        g.min[a] = c.bbox[2 * a];
+        g.max[a] = c.bbox[2 * a + 1];
+        const double d = (g.max[a] - g.min[a]) / g.res;  // grid.hpp:623-625 (int truncation)
+        if (!(d < 2097151.0)) return fail(h, HFPF_ERR_BAD_CONFIG, "axis %d: more than 2^21 cells", a);
+        g.dim[a] = (int32_t)d;
+        g.bdim[a] = (g.dim[a] + 1 + 7) / 8;  // storage is dim+1 cells, grid.hpp:626
+    }
+    g.zclip_min = c.z_clip_min;
+    g.zclip_max = c.z_clip_max;
+    g.cyl_r = c.cylinder_radius;
+    g.ball_r = (float)c.ball_radius;
+    g.K = c.K;
+    g.gate = c.gate;
+    const double B = ((double)c.K + 2.0) * g.res;  // |proj - c| <= |p - c| <= K*res + sqrt(3)*res
+    g.s1_scale = std::ldexp(1.0, pow2_exponent_for(B));
+    g.s2_scale = std::ldexp(1.0, pow2_exponent_for(B * B));
+    g.sd_scale = std::ldexp(1.0, pow2_exponent_for(g.cyl_r));
+    g.sdd_scale = std::ldexp(1.0, pow2_exponent_for(g.cyl_r * g.cyl_r));
+    const double dir_entries = (double)g.bdim[0] * (double)g.bdim[1] * (double)g.bdim[2];
+    if (dir_entries > 4.0e9) return fail(h, HFPF_ERR_BAD_CONFIG, "brick directory too large (%.3g entries)", dir_entries);
+    h->dir_entries = (size_t)dir_entries;
+    return HFPF_OK;
+}
+
+int reset_state(hfpf_handle* h)
+{
+    Tables& t = h->t;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemsetAsync(t.dir, 0, h->dir_entries * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.info, 0, h->n_slots * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.first_frame, 0xFF, h->n_slots * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.buf_head, 0, h->n_slots * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.stat_id, 0, h->n_slots * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.pre_dep, 0, h->n_slots * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.dep_tmp, 0, h->n_slots * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.occ_mask, 0, (t.max_bricks + 1) * 8 * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.stats, 0, (t.max_normals + 1) * kStatWords * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.ctr, 0, C_COUNT * 8, s));
+    h->dirty = false;
+    h->n_linked = 0;
+    h->next_frame_id = 0;
+    return HFPF_OK;
+}
+
+int alloc_tables(hfpf_handle* h)
+{
+    hfpf_config& c = h->cfg;
+    Tables& t = h->t;
+    memset(&t, 0, sizeof t);
+    if (c.max_bricks == 0) c.max_bricks = 131072;
+    if (c.max_log_points == 0) c.max_log_points = 64ull << 20;
+    if (c.max_normals == 0) c.max_normals = 8ull << 20;
+    if (c.max_frames == 0) c.max_frames = 65536;
+    if (c.max_bricks > 8388606ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_bricks must be < 2^23");
+    if (c.max_log_points > 4294967294ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_log_points must be < 2^32-1");
+    if (c.max_normals > 4294967294ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_normals must be < 2^32-1");
+    t.max_bricks = c.max_bricks;
+    t.max_log = c.max_log_points;
+    t.max_normals = c.max_normals;
+    t.max_occ = c.max_normals * 4;
+    t.max_reg = c.max_normals * (2ull * (uint64_t)c.K + 1ull);
+    t.max_dep = t.max_reg;
+    t.max_frames = c.max_frames;
+    h->n_slots = (t.max_bricks + 1) * (uint64_t)kBrickCells;
+    h->max_touched = t.max_reg;
+    int rc;
+#define ALLOC(field, count, ...)                                         \
+    if ((rc = dev_alloc(h, &t.field, (count), ##__VA_ARGS__)) != HFPF_OK) return rc;
+    ALLOC(dir, h->dir_entries, 0, false);
+    ALLOC(brick_lin, t.max_bricks + 1);
+    ALLOC(info, h->n_slots, 0, false);
+    ALLOC(first_frame, h->n_slots, 0, false);
+    ALLOC(buf_head, h->n_slots, 0, false);
+    ALLOC(stat_id, h->n_slots, 0, false);
+    ALLOC(pre_dep, h->n_slots, 0, false);
+    ALLOC(dep_tmp, h->n_slots, 0, false);
+    ALLOC(occ_mask, (t.max_bricks + 1) * 8, 0, false);
+    ALLOC(log_pt, t.max_log + 1, 0, false);
+    ALLOC(log_link, t.max_log + 1, 0, false);
+    ALLOC(occ_list, t.max_occ, 0, false);
+    ALLOC(nv_key, t.max_normals + 1, 0, false);
+    ALLOC(nv_slot, t.max_normals + 1, 0, false);
+    ALLOC(nv_c, 3 * (t.max_normals + 1), 0, false);
+    ALLOC(nv_n, 3 * (t.max_normals + 1), 0, false);
+    ALLOC(stats, (t.max_normals + 1) * kStatWords, 0, false);
+    ALLOC(reg_occ, t.max_reg, 0, false);
+    ALLOC(dep, t.max_dep, 0, false);
+    ALLOC(prereg_list, t.max_reg, 0, false);
+    ALLOC(touched_list, h->max_touched, 0, false);
+    ALLOC(cand_key, t.max_occ, 0, false);
+    ALLOC(frame_vp, 3 * t.max_frames);
+    ALLOC(ctr, C_COUNT);
+#undef ALLOC
+    return reset_state(h);
+}
+
+int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n)
+{
+    size_t bytes = 0;
+    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, 64, h->stream));
+    int rc = scratch(h, h->sort_tmp, bytes);
+    if (rc) return rc;
+    bytes = h->sort_tmp.bytes;
+    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, 64, h->stream));
+    return HFPF_OK;
+}
+
+int sort_pairs_u64(hfpf_handle* h, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, uint64_t n)
+{
+    size_t bytes = 0;
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, 64, h->stream));
+    int rc = scratch(h, h->sort_tmp, bytes);
+    if (rc) return rc;
+    bytes = h->sort_tmp.bytes;
+    HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0, 64, h->stream));
+    return HFPF_OK;
+}
+
+int acquire_stage(hfpf_handle* h, uint32_t n_frames, StageSlot** out)
+{
+    StageSlot& s = h->stage[h->stage_next];
+    h->stage_next = (h->stage_next + 1) % kStageSlots;
+    if (s.pending) {
+        HIPCHK(h, hipEventSynchronize(s.done));
+        s.pending = false;
+    }
+    if (!s.done) HIPCHK(h, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    if (s.cap < n_frames) {
+        if (s.h_pose) {
+            HIPCHK(h, hipHostFree(s.h_pose));
+            HIPCHK(h, hipHostFree(s.h_ids));
+            HIPCHK(h, hipFree(s.d_pose));
+            HIPCHK(h, hipFree(s.d_ids));
+        }
+        const uint32_t cap = std::max<uint32_t>(n_frames, 64);
+        HIPCHK(h, hipHostMalloc((void**)&s.h_pose, (size_t)cap * 12 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&s.h_ids, (size_t)cap * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(h, hipMalloc((void**)&s.d_pose, (size_t)cap * 12 * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&s.d_ids, (size_t)cap * sizeof(uint32_t)));
+        s.cap = cap;
+    }
+    *out = &s;
+    return HFPF_OK;
+}
+
+int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_frames, uint64_t frame_stride, uint32_t n_points,
+                            uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double* poses,
+                            const uint32_t* frame_ids)
+{
+    if (!dev_base || !poses || n_frames == 0) return fail(h, HFPF_ERR_BAD_ARG, "integrate: null buffer/poses or zero frames");
+    if (n_points == 0) return HFPF_OK;
+    if ((point_step & 3) || (off_x & 3) || (off_y & 3) || (off_z & 3) || (off_rgb & 3) || ((uintptr_t)dev_base & 3) || (frame_stride & 3))
+        return fail(h, HFPF_ERR_BAD_ARG, "integrate: fields must be 4-byte aligned");
+    if (std::max(std::max(off_x, off_y), std::max(off_z, off_rgb)) + 4 > point_step)
+        return fail(h, HFPF_ERR_BAD_ARG, "integrate: field offset beyond point_step");
+    if (n_frames > 65535) return fail(h, HFPF_ERR_BAD_ARG, "integrate: at most 65535 frames per call");
+    StageSlot* s = nullptr;
+    int rc = acquire_stage(h, n_frames, &s);
+    if (rc) return rc;
+    memcpy(s->h_pose, poses, (size_t)n_frames * 12 * sizeof(double));
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const uint32_t id = frame_ids ? frame_ids[f] : h->next_frame_id + f;
+        if (id >= h->t.max_frames) return fail(h, HFPF_ERR_CAPACITY, "frame id %u >= max_frames %llu", id, (unsigned long long)h->t.max_frames);
+        s->h_ids[f] = id;
+    }
+    if (!frame_ids) h->next_frame_id += n_frames;
+    HIPCHK(h, hipMemcpyAsync(s->d_pose, s->h_pose, (size_t)n_frames * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->d_ids, s->h_ids, (size_t)n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+
+    const FrameLayout lay{point_step, off_x, off_y, off_z, off_rgb};
+    const bool packed = point_step == 16 && off_x == 0 && off_y == 4 && off_z == 8 && off_rgb == 12 && ((uintptr_t)dev_base & 15) == 0 &&
+                        (frame_stride & 15) == 0;
+    const dim3 block(256);
+    const dim3 grid(std::min<unsigned>(blocks_for(n_points, 256), 4096u), n_frames);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        auto get = [&](hipEvent_t& e) -> hipError_t {
+            if (!h->ev_free.empty()) {
+                e = h->ev_free.back();
+                h->ev_free.pop_back();
+                return hipSuccess;
+            }
+            return hipEventCreate(&e);
+        };
+        HIPCHK(h, get(e0));
+        HIPCHK(h, get(e1));
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    if (packed)
+        hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, lay,
+                           (const double*)s->d_pose, (const uint32_t*)s->d_ids);
+    else
+        hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, lay,
+                           (const double*)s->d_pose, (const uint32_t*)s->d_ids);
+    HIPCHK(h, hipGetLastError());
+    if (h->timing) {
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        h->ev_pending.emplace_back(e0, e1);
+    }
+    HIPCHK(h, hipEventRecord(s->done, h->stream));
+    s->pending = true;
+    h->dirty = true;  // state_changed = true, grid.hpp:189
+    h->frames_integrated += n_frames;
+    return HFPF_OK;
+}
+
+int resolve_timing(hfpf_handle* h)
+{
+    if (h->ev_pending.empty()) return HFPF_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& pr : h->ev_pending) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, pr.first, pr.second));
+        h->t_integrate_ms += (double)ms;
+        h->n_integrate_launches++;
+        h->ev_free.push_back(pr.first);
+        h->ev_free.push_back(pr.second);
+    }
+    h->ev_pending.clear();
+    return HFPF_OK;
+}
+
+int clean_locked(hfpf_handle* h)
+{
+    Tables& t = h->t;
+    hipStream_t s = h->stream;
+    int rc = read_counters(h);
+    if (rc) return rc;
+    if ((rc = check_device_errors(h))) return rc;
+    const uint64_t n_log = std::min<uint64_t>(h->h_ctr[C_LOG], t.max_log);
+    const uint64_t n_occ = std::min<uint64_t>(h->h_ctr[C_OCC], t.max_occ);
+    const uint64_t n_normals = h->h_ctr[C_NORMALS];
+    h->dirty = false;  // state_changed = false, grid.hpp:313
+    h->clean_passes++;
+
+    if (n_log > h->n_linked) {
+        const uint64_t cnt = n_log - h->n_linked;
+        hipLaunchKernelGGL(k_link_log, dim3(blocks_for(cnt, 256)), dim3(256), 0, s, t, (uint32_t)(h->n_linked + 1), (uint32_t)n_log);
+        HIPCHK(h, hipGetLastError());
+        h->n_linked = n_log;
+    }
+    if (n_occ == 0) return HFPF_OK;
+
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull);
+    hipLaunchKernelGGL(k_gate, dim3(blocks_for(n_occ, 256)), dim3(256), 0, s, h->g, t, n_occ);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = read_counters(h))) return rc;
+    const uint64_t n_cand = h->h_ctr[C_CAND];
+    if (n_cand == 0) return HFPF_OK;
+    if (n_normals + n_cand > t.max_normals)
+        return fail(h, HFPF_ERR_CAPACITY, "normal records: %llu + %llu > max_normals %llu", (unsigned long long)n_normals,
+                    (unsigned long long)n_cand, (unsigned long long)t.max_normals);
+
+    // canonical order: ascending (x,y,z) key
+    if ((rc = scratch(h, h->keys_a, n_cand * 8))) return rc;
+    if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_cand))) return rc;
+    hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_cand, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, n_cand, n_normals);
+    const uint64_t n_steps = n_cand * (2ull * (uint64_t)h->g.K + 1ull);
+    hipLaunchKernelGGL(k_register, dim3(blocks_for(n_steps, 256)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand));
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_DEP, 0ull);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_TOUCHED, 0ull);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = read_counters(h))) return rc;
+    if ((rc = check_device_errors(h))) return rc;
+    const uint64_t n_reg = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
+    const uint64_t n_pre = std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
+    const uint64_t n_all = n_reg + n_pre;
+    if (n_all > t.max_dep) return fail(h, HFPF_ERR_CAPACITY, "dependant table: %llu entries > %llu", (unsigned long long)n_all, (unsigned long long)t.max_dep);
+    if (n_all) {
+        hipLaunchKernelGGL(k_dep_count, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
+        HIPCHK(h, hipGetLastError());
+        if ((rc = read_counters(h))) return rc;
+        const uint64_t n_touched = h->h_ctr[C_TOUCHED];
+        hipLaunchKernelGGL(k_dep_offsets, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+        hipLaunchKernelGGL(k_dep_fill, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
+        hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+        HIPCHK(h, hipGetLastError());
+    }
+    if ((rc = read_counters(h))) return rc;
+    return check_device_errors(h);
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int hfpf_abi_version(void) { return HFPF_ABI_VERSION; }
+
+void hfpf_default_config(hfpf_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->struct_size = sizeof *c;
+    c->resolution = 0.005f;  // kResolution node.cpp:91
+    const double box[6] = {-0.80, 1.80, -1.5, 1.5, 0.0, 1.0};  // launch file line 7
+    memcpy(c->bbox, box, sizeof box);
+    c->k = 2;                    // node.cpp:163
+    c->K = 3;                    // node.cpp:311
+    c->gate = 20;                // grid.hpp:352
+    c->cylinder_radius = 0.001;  // grid.hpp:36
+    c->ball_radius = 0.015;      // grid.hpp:35
+    c->z_clip_min = 0.28;        // node.cpp:92
+    c->z_clip_max = 0.6;         // node.cpp:93
+    c->device = 0;
+}
+
+const char* hfpf_last_error(const hfpf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
+{
+    if (!cfg || !out) return fail(nullptr, HFPF_ERR_BAD_ARG, "hfpf_create: null argument");
+    if (cfg->struct_size != sizeof(hfpf_config)) return fail(nullptr, HFPF_ERR_BAD_CONFIG, "hfpf_config.struct_size mismatch (ABI %d)", HFPF_ABI_VERSION);
+    *out = nullptr;
+    hfpf_handle* h = new hfpf_handle();
+    h->cfg = *cfg;
+    auto bail = [&](int rc) {
+        g_create_error = h->err;
+        for (void* p : h->allocs) (void)hipFree(p);
+        if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        delete h;
+        return rc;
+    };
+    int rc = setup_params(h);
+    if (rc) return bail(rc);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return bail(fail(h, HFPF_ERR_HIP, "no HIP device available (%s); this engine has no CPU path", hipGetErrorString(e)));
+    if (cfg->device < 0 || cfg->device >= ndev) return bail(fail(h, HFPF_ERR_BAD_CONFIG, "device %d out of range (%d devices)", cfg->device, ndev));
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e)));
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+    if ((e = hipHostMalloc((void**)&h->h_ctr, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+        return bail(fail(h, HFPF_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)));
+    memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));
+    if ((rc = alloc_tables(h))) return bail(rc);
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "sync after init: %s", hipGetErrorString(e)));
+    *out = h;
+    return HFPF_OK;
+}
+
+int hfpf_destroy(hfpf_handle* h)
+{
+    if (!h) return HFPF_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (DevBuf* b : {&h->sort_tmp, &h->keys_a, &h->keys_b, &h->vals_a, &h->vals_b, &h->rows_dev, &h->probe_a, &h->probe_b, &h->probe_c, &h->probe_d,
+                      &h->probe_e, &h->probe_f})
+        if (b->p) (void)hipFree(b->p);
+    for (auto& s : h->stage) {
+        if (s.h_pose) (void)hipHostFree(s.h_pose);
+        if (s.h_ids) (void)hipHostFree(s.h_ids);
+        if (s.d_pose) (void)hipFree(s.d_pose);
+        if (s.d_ids) (void)hipFree(s.d_ids);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (auto& f : h->fslot) {
+        if (f.h) (void)hipHostFree(f.h);
+        if (f.d) (void)hipFree(f.d);
+        if (f.done) (void)hipEventDestroy(f.done);
+    }
+    for (auto& pr : h->ev_pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    for (auto e : h->ev_free) (void)hipEventDestroy(e);
+    if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return HFPF_OK;
+}
+
+int hfpf_get_dims(const hfpf_handle* h, int32_t dims[3], double* resolution)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    if (dims) memcpy(dims, h->g.dim, 3 * sizeof(int32_t));
+    if (resolution) *resolution = h->g.res;
+    return HFPF_OK;
+}
+
+int hfpf_integrate_device(hfpf_handle* h, const void* dev_base, uint32_t n_frames, uint64_t frame_stride, uint32_t n_points, uint32_t point_step,
+                          uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double* poses, const uint32_t* frame_ids)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return integrate_device_locked(h, dev_base, n_frames, frame_stride, n_points, point_step, off_x, off_y, off_z, off_rgb, poses, frame_ids);
+}
+
+int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                   uint32_t off_rgb, const double pose[12])
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!base || !pose) return fail(h, HFPF_ERR_BAD_ARG, "integrate: null buffer or pose");
+    if (n_points == 0) {
+        h->next_frame_id++;
+        h->frames_integrated++;
+        h->dirty = true;
+        return HFPF_OK;
+    }
+    const size_t bytes = (size_t)n_points * point_step;
+    FrameSlot& f = h->fslot[h->fslot_next];
+    h->fslot_next = (h->fslot_next + 1) % kFrameSlots;
+    if (f.pending) {
+        HIPCHK(h, hipEventSynchronize(f.done));
+        f.pending = false;
+    }
+    if (!f.done) HIPCHK(h, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    if (f.cap < bytes) {
+        if (f.h) {
+            HIPCHK(h, hipHostFree(f.h));
+            HIPCHK(h, hipFree(f.d));
+            f.h = f.d = nullptr;
+        }
+        const size_t cap = (bytes + 4095) & ~(size_t)4095;
+        HIPCHK(h, hipHostMalloc(&f.h, cap, hipHostMallocDefault));
+        HIPCHK(h, hipMalloc(&f.d, cap));
+        f.cap = cap;
+    }
+    memcpy(f.h, base, bytes);  // the caller's buffer is free again when this call returns
+    HIPCHK(h, hipMemcpyAsync(f.d, f.h, bytes, hipMemcpyHostToDevice, h->stream));
+    int rc = integrate_device_locked(h, f.d, 1, 0, n_points, point_step, off_x, off_y, off_z, off_rgb, pose, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(f.done, h->stream));
+    f.pending = true;
+    return HFPF_OK;
+}
+
+int hfpf_is_dirty(hfpf_handle* h)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    return h->dirty ? 1 : 0;
+}
+
+int hfpf_clean(hfpf_handle* h)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return clean_locked(h);
+}
+
+int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
+{
+    if (!h || !rows || !n_rows) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    *rows = nullptr;
+    *n_rows = 0;
+    Tables& t = h->t;
+    int rc = read_counters(h);
+    if (rc) return rc;
+    if ((rc = check_device_errors(h))) return rc;
+    const uint64_t n = h->h_ctr[C_NORMALS];
+    if (n == 0) return HFPF_OK;
+    if ((rc = scratch(h, h->keys_a, n * 8))) return rc;
+    if ((rc = scratch(h, h->keys_b, n * 8))) return rc;
+    if ((rc = scratch(h, h->vals_a, n * 4))) return rc;
+    if ((rc = scratch(h, h->vals_b, n * 4))) return rc;
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, h->stream, t.ctr, (int)C_ROWS, 0ull);
+    hipLaunchKernelGGL(k_extract_keys, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, t, n, (uint64_t*)h->keys_a.p, (uint32_t*)h->vals_a.p);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = sort_pairs_u64(h, (uint64_t*)h->keys_a.p, (uint64_t*)h->keys_b.p, (uint32_t*)h->vals_a.p, (uint32_t*)h->vals_b.p, n))) return rc;
+    if ((rc = read_counters(h))) return rc;
+    const uint64_t nr = h->h_ctr[C_ROWS];
+    if (nr == 0) return HFPF_OK;
+    if ((rc = scratch(h, h->rows_dev, nr * sizeof(Row)))) return rc;
+    hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, nr, (const uint64_t*)h->keys_b.p,
+                       (const uint32_t*)h->vals_b.p, (Row*)h->rows_dev.p);
+    HIPCHK(h, hipGetLastError());
+    hfpf_row* host = (hfpf_row*)malloc(nr * sizeof(hfpf_row));
+    if (!host) return fail(h, HFPF_ERR_CAPACITY, "extract: host allocation of %llu rows failed", (unsigned long long)nr);
+    hipError_t e = hipMemcpyAsync(host, h->rows_dev.p, nr * sizeof(Row), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        free(host);
+        return fail(h, HFPF_ERR_HIP, "extract copy: %s", hipGetErrorString(e));
+    }
+    *rows = host;
+    *n_rows = nr;
+    return HFPF_OK;
+}
+
+void hfpf_free_rows(hfpf_row* rows) { free(rows); }
+
+int hfpf_write_pcd(const hfpf_row* rows, uint64_t n, const char* path)
+{
+    if (!path || (!rows && n)) return HFPF_ERR_BAD_ARG;
+    FILE* f = fopen(path, "w");
+    if (!f) return HFPF_ERR_IO;
+    // PCL PCDWriter::writeASCII layout for PointXYZRGBNormal (pcl::io::savePCDFileASCII, grid.hpp:485), precision 8.
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb normal_x normal_y normal_z curvature\n");
+    fprintf(f, "SIZE 4 4 4 4 4 4 4 4\nTYPE F F F U F F F F\nCOUNT 1 1 1 1 1 1 1 1\n");
+    fprintf(f, "WIDTH %llu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %llu\nDATA ascii\n", (unsigned long long)n, (unsigned long long)n);
+    for (uint64_t i = 0; i < n; i++) {
+        const hfpf_row& r = rows[i];
+        fprintf(f, "%.8g %.8g %.8g %u %.8g %.8g %.8g 0\n", r.x, r.y, r.z, r.rgb, r.nx, r.ny, r.nz);
+    }
+    const bool ok = !ferror(f);
+    return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
+}
+
+int hfpf_write_meta_csv(const hfpf_row* rows, uint64_t n, const char* path)
+{
+    if (!path || (!rows && n)) return HFPF_ERR_BAD_ARG;
+    FILE* f = fopen(path, "w");
+    if (!f) return HFPF_ERR_IO;
+    fprintf(f, "Id,sdx,sdy,sdz,mean distance from normal, distance from normal sd, points in cylinder\n");  // grid.hpp:462 verbatim
+    for (uint64_t i = 0; i < n; i++) {
+        const hfpf_row& r = rows[i];  // default ostream float formatting = %g (6 significant digits), grid.hpp:478
+        fprintf(f, "%llu,%g,%g,%g,%g,%g,%d\n", (unsigned long long)i, r.sdx, r.sdy, r.sdz, r.mean_dist, r.sd_dist, (int)r.count);
+    }
+    const bool ok = !ferror(f);
+    return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
+}
+
+int hfpf_clear(hfpf_handle* h)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = reset_state(h);
+    h->dirty = true;  // clearVoxels sets state_changed, grid.hpp:169
+    return rc;
+}
+
+int hfpf_sync(hfpf_handle* h)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = read_counters(h);
+    if (rc) return rc;
+    return check_device_errors(h);
+}
+
+int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)
+{
+    if (!h || !out) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = read_counters(h);
+    if (rc) return rc;
+    const unsigned long long* c = h->h_ctr;
+    out->points_presented = c[C_PRESENTED];
+    out->points_zclip_pass = c[C_ZPASS];
+    out->points_in_bbox = c[C_INBOX];
+    out->points_buffered = c[C_BUFFERED];
+    out->dep_pairs_tested = c[C_DEP_TESTED];
+    out->dep_pairs_member = c[C_DEP_MEMBER];
+    out->voxels_occupied = c[C_OCC];
+    out->voxels_with_normal = c[C_NORMALS];
+    out->bricks_allocated = std::min<uint64_t>(c[C_BRICKS], h->t.max_bricks);
+    out->registrations = c[C_REG];
+    out->dep_entries = c[C_DEP];
+    out->frames_integrated = h->frames_integrated;
+    out->clean_passes = h->clean_passes;
+    out->device_bytes = h->device_bytes;
+    return HFPF_OK;
+}
+
+int hfpf_get_occupied(hfpf_handle* h, int32_t* xyz, uint64_t cap, uint64_t* n_out)
+{
+    if (!h || !n_out) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = read_counters(h);
+    if (rc) return rc;
+    const uint64_t n = std::min<uint64_t>(h->h_ctr[C_OCC], h->t.max_occ);
+    *n_out = n;
+    if (!xyz || n == 0) return HFPF_OK;
+    if ((rc = scratch(h, h->keys_a, n * 8))) return rc;
+    if ((rc = scratch(h, h->keys_b, n * 8))) return rc;
+    hipLaunchKernelGGL(k_occupied_keys, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, h->t, n, (uint64_t*)h->keys_a.p);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = sort_keys_u64(h, (uint64_t*)h->keys_a.p, (uint64_t*)h->keys_b.p, n))) return rc;
+    std::vector<uint64_t> keys(n);
+    HIPCHK(h, hipMemcpyAsync(keys.data(), h->keys_b.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (uint64_t i = 0; i < std::min(n, cap); i++) key_coords(keys[i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return HFPF_OK;
+}
+
+int hfpf_device_alloc(hfpf_handle* h, uint64_t bytes, void** dev_ptr)
+{
+    if (!h || !dev_ptr) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMalloc(dev_ptr, (size_t)std::max<uint64_t>(bytes, 1)));
+    return HFPF_OK;
+}
+
+int hfpf_device_free(hfpf_handle* h, void* dev_ptr)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(dev_ptr));
+    return HFPF_OK;
+}
+
+int hfpf_device_upload(hfpf_handle* h, void* dev_dst, const void* host_src, uint64_t bytes)
+{
+    if (!h || !dev_dst || !host_src) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpy(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice));
+    return HFPF_OK;
+}
+
+int hfpf_kernel_timing(hfpf_handle* h, int enable)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = resolve_timing(h);
+    if (rc) return rc;
+    h->timing = enable != 0;
+    if (enable) {
+        h->t_integrate_ms = 0;
+        h->n_integrate_launches = 0;
+    }
+    return HFPF_OK;
+}
+
+int hfpf_get_kernel_time(hfpf_handle* h, int kernel_id, double* total_ms, uint64_t* launches)
+{
+    if (!h || kernel_id != 0) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = resolve_timing(h);
+    if (rc) return rc;
+    if (total_ms) *total_ms = h->t_integrate_ms;
+    if (launches) *launches = h->n_integrate_launches;
+    return HFPF_OK;
+}
+
+// ---- leaf probes (include/hfpf_probe.h) ----------------------------------------------------------
+#define PROBE_UP(buf, src, bytes)                                                  \
+    if ((rc = scratch(h, buf, (bytes)))) return rc;                                \
+    HIPCHK(h, hipMemcpyAsync(buf.p, (src), (bytes), hipMemcpyHostToDevice, h->stream));
+#define PROBE_DOWN(dst, buf, bytes) HIPCHK(h, hipMemcpyAsync((dst), buf.p, (bytes), hipMemcpyDeviceToHost, h->stream));
+
+int hfpf_probe_points(hfpf_handle* h, const double pose[12], const float* xyz, uint64_t n, float* q_out, int32_t* idx_out, uint8_t* flags_out)
+{
+    if (!h || !pose || !xyz || !q_out || !idx_out || !flags_out) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (n == 0) return HFPF_OK;
+    int rc;
+    PROBE_UP(h->probe_a, pose, 12 * sizeof(double));
+    PROBE_UP(h->probe_b, xyz, n * 12);
+    if ((rc = scratch(h, h->probe_c, n * 12))) return rc;
+    if ((rc = scratch(h, h->probe_d, n * 12))) return rc;
+    if ((rc = scratch(h, h->probe_e, n))) return rc;
+    hipLaunchKernelGGL(k_probe_points, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, (const double*)h->probe_a.p, (const float*)h->probe_b.p, n,
+                       (float*)h->probe_c.p, (int32_t*)h->probe_d.p, (uint8_t*)h->probe_e.p);
+    HIPCHK(h, hipGetLastError());
+    PROBE_DOWN(q_out, h->probe_c, n * 12);
+    PROBE_DOWN(idx_out, h->probe_d, n * 12);
+    PROBE_DOWN(flags_out, h->probe_e, n);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HFPF_OK;
+}
+
+int hfpf_probe_normals(hfpf_handle* h, uint64_t n, const int32_t* cells, const uint8_t* occ, const float* vps, float* normals_out, int32_t* totals_out)
+{
+    if (!h || !cells || !occ || !vps || !normals_out || !totals_out) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (n == 0) return HFPF_OK;
+    int rc;
+    PROBE_UP(h->probe_a, cells, n * 12);
+    PROBE_UP(h->probe_b, occ, n * 125);
+    PROBE_UP(h->probe_c, vps, n * 12);
+    if ((rc = scratch(h, h->probe_d, n * 12))) return rc;
+    if ((rc = scratch(h, h->probe_e, n * 4))) return rc;
+    hipLaunchKernelGGL(k_probe_normals, dim3(blocks_for(n, 64)), dim3(64), 0, h->stream, h->g, n, (const int32_t*)h->probe_a.p, (const uint8_t*)h->probe_b.p,
+                       (const float*)h->probe_c.p, (float*)h->probe_d.p, (int32_t*)h->probe_e.p);
+    HIPCHK(h, hipGetLastError());
+    PROBE_DOWN(normals_out, h->probe_d, n * 12);
+    PROBE_DOWN(totals_out, h->probe_e, n * 4);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HFPF_OK;
+}
+
+int hfpf_probe_project(hfpf_handle* h, uint64_t n, const float* pts, const float* centres, const float* normals, float* proj_out, double* dist_out,
+                       uint8_t* member_out)
+{
+    if (!h || !pts || !centres || !normals || !proj_out || !dist_out || !member_out) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (n == 0) return HFPF_OK;
+    int rc;
+    PROBE_UP(h->probe_a, pts, n * 12);
+    PROBE_UP(h->probe_b, centres, n * 12);
+    PROBE_UP(h->probe_c, normals, n * 12);
+    if ((rc = scratch(h, h->probe_d, n * 12))) return rc;
+    if ((rc = scratch(h, h->probe_e, n * 8))) return rc;
+    if ((rc = scratch(h, h->probe_f, n))) return rc;
+    hipLaunchKernelGGL(k_probe_project, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, n, (const float*)h->probe_a.p, (const float*)h->probe_b.p,
+                       (const float*)h->probe_c.p, (float*)h->probe_d.p, (double*)h->probe_e.p, (uint8_t*)h->probe_f.p);
+    HIPCHK(h, hipGetLastError());
+    PROBE_DOWN(proj_out, h->probe_d, n * 12);
+    PROBE_DOWN(dist_out, h->probe_e, n * 8);
+    PROBE_DOWN(member_out, h->probe_f, n);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HFPF_OK;
+}
+
+int hfpf_probe_trig(hfpf_handle* h, uint64_t n, const float* y, const float* x, float* atan2_out, float* cos_out, float* sin_out)
+{
+    if (!h || !y || !x || !atan2_out || !cos_out || !sin_out) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (n == 0) return HFPF_OK;
+    int rc;
+    PROBE_UP(h->probe_a, y, n * 4);
+    PROBE_UP(h->probe_b, x, n * 4);
+    if ((rc = scratch(h, h->probe_c, n * 4))) return rc;
+    if ((rc = scratch(h, h->probe_d, n * 4))) return rc;
+    if ((rc = scratch(h, h->probe_e, n * 4))) return rc;
+    hipLaunchKernelGGL(k_probe_trig, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, n, (const float*)h->probe_a.p, (const float*)h->probe_b.p,
+                       (float*)h->probe_c.p, (float*)h->probe_d.p, (float*)h->probe_e.p);
+    HIPCHK(h, hipGetLastError());
+    PROBE_DOWN(atan2_out, h->probe_c, n * 4);
+    PROBE_DOWN(cos_out, h->probe_d, n * 4);
+    PROBE_DOWN(sin_out, h->probe_e, n * 4);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HFPF_OK;
+}
+
+}  // extern "C"

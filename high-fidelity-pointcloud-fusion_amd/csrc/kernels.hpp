@@ -1,0 +1,519 @@
+// csrc/kernels.hpp -- HIP kernels of the fusion path (gfx950, 64-wide waves).
+//
+//   K1 k_integrate        decode + z-clip + SE(3) + bbox clip + voxel index + insert/append + dependant updates
+//                         (node.cpp:190-214,251-255,289; grid.hpp:194-277)
+//   K3 k_gate             5x5x5 occupancy count and the >gate test            (grid.hpp:322-352)
+//   K4 k_normal           plane fit on occupied neighbour centres, orientation (grid.hpp:356-398)
+//   K5 k_register         +-K line walk, dependant registration, buffer replay (grid.hpp:403-450)
+//      k_dep_*            rebuild of the per-cell dependant table
+//   K6 k_extract_*        ordered compaction of normal_found voxels            (grid.hpp:463-480)
+#pragma once
+#include "stats.hpp"
+
+namespace hfpf {
+
+struct FrameLayout {
+    uint32_t point_step, off_x, off_y, off_z, off_rgb;
+};
+
+// ------------------------------------------------------------------------------------------------
+// K1: one thread per input point, grid.y = frame of the batch.  Loop trip counts are wave-uniform so
+// the ballot/shuffle helpers stay convergent.
+template <bool PACKED16>
+__global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
+                                                   const uint64_t frame_stride, const uint32_t n_pts, const FrameLayout lay,
+                                                   const double* __restrict__ poses, const uint32_t* __restrict__ frame_ids)
+{
+    const uint32_t f = blockIdx.y;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = poses[12 * f + i];
+    const uint32_t fid = frame_ids[f];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (fid < t.max_frames) {  // viewpoint = float(translation), node.cpp:290
+            t.frame_vp[3 * (uint64_t)fid + 0] = (float)T[3];
+            t.frame_vp[3 * (uint64_t)fid + 1] = (float)T[7];
+            t.frame_vp[3 * (uint64_t)fid + 2] = (float)T[11];
+        } else {
+            atomicOr(&t.ctr[C_ERR], (unsigned long long)E_FRAME);
+        }
+    }
+    const uint8_t* __restrict__ base = frames + (uint64_t)f * frame_stride;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t c_present = 0, c_z = 0, c_in = 0, c_buf = 0, c_tested = 0, c_member = 0;
+
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_pts; i0 += stride) {
+        const uint32_t i = i0 + lane;
+        bool act = i < n_pts;
+        float x = 0.f, y = 0.f, z = 0.f;
+        uint32_t rgb = 0;
+        if (act) {
+            if (PACKED16) {
+                const float4 v = reinterpret_cast<const float4*>(base)[i];
+                x = v.x;
+                y = v.y;
+                z = v.z;
+                rgb = __float_as_uint(v.w);
+            } else {
+                const uint8_t* rec = base + (uint64_t)i * lay.point_step;
+                x = *reinterpret_cast<const float*>(rec + lay.off_x);
+                y = *reinterpret_cast<const float*>(rec + lay.off_y);
+                z = *reinterpret_cast<const float*>(rec + lay.off_z);
+                rgb = *reinterpret_cast<const uint32_t*>(rec + lay.off_rgb);
+            }
+        }
+        c_present += act;
+        act = act && zclip_pass(g, z);
+        c_z += act;
+        const F3 q = transform_point(T, x, y, z);
+        int32_t ix, iy, iz;
+        voxel_coords(g, q, ix, iy, iz);
+        // A NaN coordinate passes validPoints in the reference and then indexes out of bounds (crash); dropped here.
+        act = act && valid_point(g, q) && ix != INT_MIN && iy != INT_MIN && iz != INT_MIN;
+        c_in += act;
+
+        const uint32_t bidx = act ? brick_index(g, ix, iy, iz) : 0u;
+        const uint32_t b = brick_acquire_wave(t, bidx, act);
+        act = act && b != 0;
+        const uint32_t slot = b * kBrickCells + local_index(ix, iy, iz);
+        const uint64_t info = act ? t.info[slot] : 0ull;
+
+        // first occupancy (grid.hpp:219-243)
+        bool first = false;
+        if (act && !(info & kOcc)) {
+            const unsigned int old = atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
+            first = !(old & 1u);
+            if (first) atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (ix & 7)]),
+                                1ull << (((iy & 7) << 3) | (iz & 7)));
+        }
+        const unsigned long long oi = wave_reserve(&t.ctr[C_OCC], first);
+        if (first) {
+            if (oi < t.max_occ) t.occ_list[oi] = slot;
+            else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
+        }
+        // viewpoint latch = smallest frame id that touched the cell (grid.hpp:229,238)
+        if (act && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
+
+        // buffer while the voxel has no normal (grid.hpp:210-211,230,239)
+        const bool buf = act && !(info & kNormal);
+        const unsigned long long li = wave_reserve(&t.ctr[C_LOG], buf);
+        if (buf) {
+            if (li < t.max_log) {
+                t.log_pt[li + 1] = make_float4(q.x, q.y, q.z, __uint_as_float(rgb));
+                t.log_link[li + 1] = slot;
+            } else {
+                atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
+            }
+        }
+        c_buf += buf;
+
+        // dependant updates (grid.hpp:244-277)
+        if (act) {
+            const uint32_t cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+            const uint64_t off = info >> kDepOffShift;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const DepEntry e = t.dep[off + j];
+                F3 proj;
+                double dist;
+                c_tested++;
+                if (cylinder_member(g, q, F3{e.cx, e.cy, e.cz}, F3{e.nx, e.ny, e.nz}, proj, dist)) {
+                    c_member++;
+                    StatDelta d;
+                    stat_delta_zero(d);
+                    stat_delta_add(d, g, proj, F3{e.cx, e.cy, e.cz}, dist, rgb);
+                    stat_flush(&t.stats[(uint64_t)e.sid * kStatWords], d);
+                }
+            }
+        }
+    }
+    wave_count(&t.ctr[C_PRESENTED], c_present);
+    wave_count(&t.ctr[C_ZPASS], c_z);
+    wave_count(&t.ctr[C_INBOX], c_in);
+    wave_count(&t.ctr[C_BUFFERED], c_buf);
+    wave_count(&t.ctr[C_DEP_TESTED], c_tested);
+    wave_count(&t.ctr[C_DEP_MEMBER], c_member);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Link the log entries appended since the last clean into their cells' chains.
+__global__ __launch_bounds__(256) void k_link_log(const Tables t, const uint32_t first, const uint32_t last)
+{
+    const uint64_t e = (uint64_t)first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > last) return;
+    const uint32_t slot = t.log_link[e];
+    t.log_link[e] = atomicExch(&t.buf_head[slot], (uint32_t)e);
+}
+
+// 125-bit occupancy stencil around (x,y,z): bit d = ((dx+2)*5 + (dy+2))*5 + (dz+2), the setK table order
+// (grid.hpp:138-149); only cells with validCoord (grid.hpp:337) can be set.
+__device__ inline void neighbourhood(const GridParams& g, const Tables& t, int32_t x, int32_t y, int32_t z, uint64_t& lo, uint64_t& hi)
+{
+    lo = 0;
+    hi = 0;
+    const int32_t y0 = max(y - 2, 0), y1 = min(y + 2, g.dim[1] - 1);
+    const int32_t z0 = max(z - 2, 0), z1 = min(z + 2, g.dim[2] - 1);
+    if (y0 > y1 || z0 > z1) return;
+    for (int a = -2; a <= 2; a++) {
+        const int32_t xx = x + a;
+        if (xx < 0 || xx >= g.dim[0]) continue;
+        for (int32_t by = y0 >> 3; by <= (y1 >> 3); by++)
+            for (int32_t bz = z0 >> 3; bz <= (z1 >> 3); bz++) {
+                const uint32_t b = t.dir[((uint32_t)(xx >> 3) * (uint32_t)g.bdim[1] + (uint32_t)by) * (uint32_t)g.bdim[2] + (uint32_t)bz];
+                if (b == 0 || b == kLock) continue;
+                const uint64_t m = t.occ_mask[(uint64_t)b * 8 + (xx & 7)];
+                if (m == 0) continue;
+                const int32_t ya = max(y0, by * 8), yb = min(y1, by * 8 + 7);
+                const int32_t za = max(z0, bz * 8), zb = min(z1, bz * 8 + 7);
+                for (int32_t yy = ya; yy <= yb; yy++)
+                    for (int32_t zz = za; zz <= zb; zz++)
+                        if ((m >> (((yy & 7) << 3) | (zz & 7))) & 1ull) {
+                            const int d = ((a + 2) * 5 + (yy - y + 2)) * 5 + (zz - z + 2);
+                            if (d < 64) lo |= 1ull << d;
+                            else hi |= 1ull << (d - 64);
+                        }
+            }
+    }
+}
+
+// K3: every occupied cell without a normal is a candidate (the reference's unprocessed_data_ set is
+// a superset whose extra members fail the same gate, grid.hpp:315,352).
+__global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t, const uint64_t n_occ)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool pass = false;
+    uint64_t key = 0;
+    if (j < n_occ) {
+        const uint32_t slot = t.occ_list[j];
+        if (!(t.info[slot] & kNormal)) {
+            int32_t x, y, z;
+            slot_coords(g, t, slot, x, y, z);
+            uint64_t lo, hi;
+            neighbourhood(g, t, x, y, z, lo, hi);
+            const int total = __popcll(lo) + __popcll(hi);
+            pass = total > g.gate;
+            key = make_key(x, y, z);
+        }
+    }
+    const unsigned long long ci = wave_reserve(&t.ctr[C_CAND], pass);
+    if (pass) t.cand_key[ci] = key;  // capacity = max_occ >= n_occ
+}
+
+// K4: one thread per candidate, in ascending key order; record id = base + rank + 1.
+__global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables t, const uint64_t* __restrict__ sorted_keys,
+                                                const uint64_t n_cand, const uint64_t base)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_cand) return;
+    const uint64_t key = sorted_keys[r];
+    int32_t x, y, z;
+    key_coords(key, x, y, z);
+    const uint32_t slot = slot_lookup(g, t, x, y, z);
+    uint64_t lo, hi;
+    neighbourhood(g, t, x, y, z, lo, hi);
+    Moments m;
+    m.clear();
+    int total = 0;
+    for (int d = 0; d < 125; d++) {
+        const bool set = d < 64 ? ((lo >> d) & 1ull) : ((hi >> (d - 64)) & 1ull);
+        if (!set) continue;
+        const int a = d / 25 - 2, bq = (d / 5) % 5 - 2, c = d % 5 - 2;
+        m.add(voxel_center(g, x + a, y + bq, z + c));  // grid.hpp:364-369
+        total++;
+    }
+    F3 normal = m.normal(total);
+    const F3 centre = voxel_center(g, x, y, z);  // grid.hpp:391
+    const uint32_t ff = t.first_frame[slot];
+    F3 vp = {0.f, 0.f, 0.f};
+    if (ff != kNoFrame && ff < t.max_frames) vp = F3{t.frame_vp[3 * (uint64_t)ff], t.frame_vp[3 * (uint64_t)ff + 1], t.frame_vp[3 * (uint64_t)ff + 2]};
+    normal = orient_normal(normal, vp, centre);
+    const uint64_t nid = base + r + 1;
+    t.nv_key[nid] = key;
+    t.nv_slot[nid] = slot;
+    t.nv_c[3 * nid + 0] = centre.x;
+    t.nv_c[3 * nid + 1] = centre.y;
+    t.nv_c[3 * nid + 2] = centre.z;
+    t.nv_n[3 * nid + 0] = normal.x;
+    t.nv_n[3 * nid + 1] = normal.y;
+    t.nv_n[3 * nid + 2] = normal.z;
+    t.stat_id[slot] = (uint32_t)nid;
+    atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 2u);  // normal_found, grid.hpp:398
+}
+
+// K5: one thread per (new normal, line step).  Occupancy is frozen during a clean pass, so the steps are
+// independent; "last registrant wins" on unoccupied cells (grid.hpp:443-449) is an atomicMax over
+// record ids, which ascend with the canonical key order inside a pass and across passes.
+__global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand, const uint64_t base)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t steps = 2u * (uint32_t)g.K + 1u;
+    const uint64_t r = idx / steps;
+    const int i = (int)(idx % steps) - g.K;
+    bool want = r < n_cand;
+    uint64_t nid = 0;
+    F3 c = {0, 0, 0}, n = {0, 0, 0};
+    int32_t xx = 0, yy = 0, zz = 0;
+    if (want) {
+        nid = base + r + 1;
+        c = F3{t.nv_c[3 * nid], t.nv_c[3 * nid + 1], t.nv_c[3 * nid + 2]};
+        n = F3{t.nv_n[3 * nid], t.nv_n[3 * nid + 1], t.nv_n[3 * nid + 2]};
+        const F3 nb = line_step(g, c, n, i);  // grid.hpp:405
+        want = valid_point(g, nb);            // grid.hpp:406
+        voxel_coords(g, nb, xx, yy, zz);      // grid.hpp:409
+        want = want && xx != INT_MIN && yy != INT_MIN && zz != INT_MIN && valid_coord(g, xx, yy, zz);  // grid.hpp:410
+    }
+    const uint32_t bidx = want ? brick_index(g, xx, yy, zz) : 0u;
+    const uint32_t b = brick_acquire_wave(t, bidx, want);
+    want = want && b != 0;
+    const uint32_t slot = b * kBrickCells + local_index(xx, yy, zz);
+    const bool occ = want && (t.info[slot] & kOcc);
+    const bool unocc = want && !occ;
+
+    const unsigned long long ri = wave_reserve(&t.ctr[C_REG], occ);
+    if (occ) {
+        if (ri < t.max_reg) t.reg_occ[ri] = make_uint2(slot, (uint32_t)nid);  // dependants.push_back, grid.hpp:417
+        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
+    }
+    bool newpre = false;
+    if (unocc) newpre = atomicMax(&t.pre_dep[slot], (uint32_t)nid) == 0u;
+    const unsigned long long pi = wave_reserve(&t.ctr[C_PREREG], newpre);
+    if (newpre) {
+        if (pi < t.max_reg) t.prereg_list[pi] = slot;
+        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
+    }
+    if (occ) {  // replay the cell's buffered points through this voxel's cylinder (grid.hpp:418-440)
+        StatDelta d;
+        stat_delta_zero(d);
+        uint32_t e = t.buf_head[slot];
+        while (e) {
+            const float4 p = t.log_pt[e];
+            F3 proj;
+            double dist;
+            if (cylinder_member(g, F3{p.x, p.y, p.z}, c, n, proj, dist)) stat_delta_add(d, g, proj, c, dist, __float_as_uint(p.w));
+            e = t.log_link[e];
+        }
+        if (d.v[SW_COUNT]) stat_flush(&t.stats[nid * kStatWords], d);
+    }
+}
+
+// ---- dependant table rebuild --------------------------------------------------------------------
+__device__ __forceinline__ uint32_t reg_slot(const Tables& t, uint64_t j, uint64_t n_reg) { return j < n_reg ? t.reg_occ[j].x : t.prereg_list[j - n_reg]; }
+
+__global__ __launch_bounds__(256) void k_dep_count(const Tables t, const uint64_t n_reg, const uint64_t n_pre)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool fresh = false;
+    uint32_t slot = 0;
+    if (j < n_reg + n_pre) {
+        slot = reg_slot(t, j, n_reg);
+        fresh = atomicAdd(&t.dep_tmp[slot], 1u) == 0u;
+    }
+    const unsigned long long ti = wave_reserve(&t.ctr[C_TOUCHED], fresh);
+    if (fresh) t.touched_list[ti] = slot;  // capacity 2*max_reg >= n_reg + n_pre
+}
+
+__global__ __launch_bounds__(256) void k_dep_offsets(const Tables t, const uint64_t n_touched)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_touched) return;
+    const uint32_t slot = t.touched_list[j];
+    uint32_t cnt = t.dep_tmp[slot];
+    const unsigned long long off = atomicAdd(&t.ctr[C_DEP], (unsigned long long)cnt);
+    if (cnt > kDepCntMask) {
+        atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEPCNT);
+        cnt = (uint32_t)kDepCntMask;
+    }
+    t.info[slot] = (t.info[slot] & 3ull) | ((uint64_t)cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
+    t.dep_tmp[slot] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_dep_fill(const Tables t, const uint64_t n_reg, const uint64_t n_pre)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_reg + n_pre) return;
+    const uint32_t slot = reg_slot(t, j, n_reg);
+    const uint32_t nid = j < n_reg ? t.reg_occ[j].y : t.pre_dep[slot];
+    const uint64_t info = t.info[slot];
+    const uint32_t k = atomicAdd(&t.dep_tmp[slot], 1u);
+    if (k >= ((info >> kDepCntShift) & kDepCntMask)) return;  // clamped list
+    DepEntry e;
+    e.sid = nid;
+    e.cx = t.nv_c[3 * (uint64_t)nid];
+    e.cy = t.nv_c[3 * (uint64_t)nid + 1];
+    e.cz = t.nv_c[3 * (uint64_t)nid + 2];
+    e.nx = t.nv_n[3 * (uint64_t)nid];
+    e.ny = t.nv_n[3 * (uint64_t)nid + 1];
+    e.nz = t.nv_n[3 * (uint64_t)nid + 2];
+    e.pad = 0;
+    t.dep[(info >> kDepOffShift) + k] = e;
+}
+
+__global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_t n_touched)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_touched) t.dep_tmp[t.touched_list[j]] = 0;
+}
+
+// ---- K6 extract -----------------------------------------------------------------------------------
+// Keys of the records that downloadData would emit: x<xdim && y<ydim && z<zdim (grid.hpp:463-465);
+// others get the all-ones key and sort to the end.
+__global__ __launch_bounds__(256) void k_extract_keys(const GridParams g, const Tables t, const uint64_t n_normals,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t valid = 0;
+    if (j < n_normals) {
+        const uint64_t nid = j + 1;
+        const uint64_t key = t.nv_key[nid];
+        int32_t x, y, z;
+        key_coords(key, x, y, z);
+        valid = valid_coord(g, x, y, z) ? 1u : 0u;
+        keys[j] = valid ? key : ~0ull;
+        vals[j] = (uint32_t)nid;
+    }
+    wave_count(&t.ctr[C_ROWS], valid);
+}
+
+struct Row {  // = hfpf_row
+    int32_t ix, iy, iz;
+    uint32_t count;
+    float x, y, z;
+    float nx, ny, nz;
+    float sdx, sdy, sdz;
+    float mean_dist, sd_dist;
+    uint32_t rgb;
+};
+static_assert(sizeof(Row) == 64, "row is 64 bytes");
+
+__global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const Tables t, const uint64_t n_rows,
+                                                      const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                      Row* __restrict__ rows)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows) return;
+    const uint64_t nid = vals[j];
+    Row r;
+    key_coords(keys[j], r.ix, r.iy, r.iz);
+    const long long* s = reinterpret_cast<const long long*>(&t.stats[nid * kStatWords]);
+    const long long cnt = s[SW_COUNT];
+    r.count = (uint32_t)cnt;
+    r.nx = t.nv_n[3 * nid];
+    r.ny = t.nv_n[3 * nid + 1];
+    r.nz = t.nv_n[3 * nid + 2];
+    if (cnt <= 0) {  // count==0 rows emit the zero centroid (grid.hpp:472-476)
+        r.x = r.y = r.z = 0.f;
+        r.sdx = r.sdy = r.sdz = 0.f;
+        r.mean_dist = r.sd_dist = 0.f;
+        r.rgb = 0;
+    } else {
+        const double inv = 1.0 / (double)cnt;
+        const double mx = ((double)s[SW_S1 + 0] / g.s1_scale) * inv;
+        const double my = ((double)s[SW_S1 + 1] / g.s1_scale) * inv;
+        const double mz = ((double)s[SW_S1 + 2] / g.s1_scale) * inv;
+        r.x = (float)((double)t.nv_c[3 * nid] + mx);
+        r.y = (float)((double)t.nv_c[3 * nid + 1] + my);
+        r.z = (float)((double)t.nv_c[3 * nid + 2] + mz);
+        double vx = ((double)s[SW_S2 + 0] / g.s2_scale) * inv - mx * mx;
+        double vy = ((double)s[SW_S2 + 1] / g.s2_scale) * inv - my * my;
+        double vz = ((double)s[SW_S2 + 2] / g.s2_scale) * inv - mz * mz;
+        const double md = ((double)s[SW_D] / g.sd_scale) * inv;
+        double vd = ((double)s[SW_DD] / g.sdd_scale) * inv - md * md;
+        if (cnt == 1) vx = vy = vz = vd = 0.0;  // the recurrence gives exactly 0 for a single sample
+        r.sdx = (float)fmax(vx, 0.0);
+        r.sdy = (float)fmax(vy, 0.0);
+        r.sdz = (float)fmax(vz, 0.0);
+        r.mean_dist = (float)md;
+        r.sd_dist = (float)fmax(vd, 0.0);
+        const uint32_t cr = (uint32_t)(((double)s[SW_RGB + 0] * inv) + 0.5);
+        const uint32_t cg = (uint32_t)(((double)s[SW_RGB + 1] * inv) + 0.5);
+        const uint32_t cb = (uint32_t)(((double)s[SW_RGB + 2] * inv) + 0.5);
+        r.rgb = (min(cr, 255u) << 16) | (min(cg, 255u) << 8) | min(cb, 255u);
+    }
+    rows[j] = r;
+}
+
+// Diagnostic: keys of every occupied cell.
+__global__ __launch_bounds__(256) void k_occupied_keys(const GridParams g, const Tables t, const uint64_t n_occ, uint64_t* __restrict__ keys)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_occ) return;
+    int32_t x, y, z;
+    slot_coords(g, t, t.occ_list[j], x, y, z);
+    keys[j] = make_key(x, y, z);
+}
+
+// ---- leaf probes (tests only; same device functions as the kernels above) -------------------------
+__global__ void k_probe_points(const GridParams g, const double* __restrict__ pose, const float* __restrict__ xyz, const uint64_t n,
+                               float* __restrict__ q_out, int32_t* __restrict__ idx_out, uint8_t* __restrict__ flags_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double T[12];
+    for (int k = 0; k < 12; k++) T[k] = pose[k];
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const F3 q = transform_point(T, x, y, z);
+    int32_t ix, iy, iz;
+    voxel_coords(g, q, ix, iy, iz);
+    q_out[3 * i] = q.x;
+    q_out[3 * i + 1] = q.y;
+    q_out[3 * i + 2] = q.z;
+    idx_out[3 * i] = ix;
+    idx_out[3 * i + 1] = iy;
+    idx_out[3 * i + 2] = iz;
+    flags_out[i] = (zclip_pass(g, z) ? 1 : 0) | (valid_point(g, q) ? 2 : 0);
+}
+
+__global__ void k_probe_normals(const GridParams g, const uint64_t n, const int32_t* __restrict__ cells, const uint8_t* __restrict__ occ,
+                                const float* __restrict__ vps, float* __restrict__ normals_out, int32_t* __restrict__ totals_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t x = cells[3 * i], y = cells[3 * i + 1], z = cells[3 * i + 2];
+    Moments m;
+    m.clear();
+    int total = 0;
+    for (int d = 0; d < 125; d++) {
+        const int a = d / 25 - 2, b = (d / 5) % 5 - 2, c = d % 5 - 2;
+        if (!occ[125 * i + d] || !valid_coord(g, x + a, y + b, z + c)) continue;
+        m.add(voxel_center(g, x + a, y + b, z + c));
+        total++;
+    }
+    totals_out[i] = total;
+    F3 nrm = {0, 0, 0};
+    if (total >= 3) {
+        nrm = m.normal(total);
+        nrm = orient_normal(nrm, F3{vps[3 * i], vps[3 * i + 1], vps[3 * i + 2]}, voxel_center(g, x, y, z));
+    }
+    normals_out[3 * i] = nrm.x;
+    normals_out[3 * i + 1] = nrm.y;
+    normals_out[3 * i + 2] = nrm.z;
+}
+
+__global__ void k_probe_project(const GridParams g, const uint64_t n, const float* __restrict__ pts, const float* __restrict__ centres,
+                                const float* __restrict__ normals, float* __restrict__ proj_out, double* __restrict__ dist_out,
+                                uint8_t* __restrict__ member_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 proj;
+    double dist;
+    const bool mem = cylinder_member(g, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, F3{centres[3 * i], centres[3 * i + 1], centres[3 * i + 2]},
+                                     F3{normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]}, proj, dist);
+    proj_out[3 * i] = proj.x;
+    proj_out[3 * i + 1] = proj.y;
+    proj_out[3 * i + 2] = proj.z;
+    dist_out[i] = dist;
+    member_out[i] = mem ? 1 : 0;
+}
+
+__global__ void k_probe_trig(const uint64_t n, const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ a_out,
+                             float* __restrict__ c_out, float* __restrict__ s_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    a_out[i] = det_atan2f(y[i], x[i]);
+    c_out[i] = det_cosf(x[i]);
+    s_out[i] = det_sinf(x[i]);
+}
+
+}  // namespace hfpf

@@ -1,0 +1,233 @@
+// csrc/tables.hpp -- HBM layout of the occupancy grid and the device-side lookup / allocation helpers.
+//
+// Layout (ours; the reference keeps vector<vector<vector<Voxel>>> + heap VoxelInfo, grid.hpp:51-82,108):
+//
+//   dir[bdim.x*bdim.y*bdim.z]  u32   brick directory, direct-mapped over the bounded bbox (a perfect
+//                                    hash: the bbox is a required launch parameter, node.cpp:451).
+//                                    0 = untouched, kLock = being allocated, else brick id (1-based).
+//   brick b, cell (lx,ly,lz)         slot = b*512 + (lx<<6 | ly<<3 | lz); brick 0 is a permanent
+//                                    all-zero "null brick" so a lookup of an untouched region needs no branch.
+//   per slot:  info u64              bit0 occupied (Voxel::occupied), bit1 normal_found,
+//                                    bits 2..17 dependant count, bits 18..63 offset into dep[]
+//              first_frame u32       smallest frame id that touched the cell (-> VoxelInfo::viewpoint, grid.hpp:229,238)
+//              buf_head u32          head of the cell's chain in the point log (VoxelInfo::buffer)
+//              stat_id u32           1-based id of the cell's normal/statistics record, 0 = none
+//              pre_dep u32           the one dependant registered while the cell was unoccupied
+//                                    (grid.hpp:443-449 overwrite semantics: last registrant wins)
+//              dep_tmp u32           scratch for the dependant-table rebuild
+//   per brick: occ_mask[8] u64       occupancy bits, one u64 per x-plane (bit = ly*8+lz): the 5x5x5 stencil
+//                                    of grid.hpp:334-349 becomes <= 20 u64 loads.
+//   point log: log_pt float4 (x,y,z,rgb bits) + log_link u32 (slot until linked, then `next`): the
+//              reference's per-voxel buffers (grid.hpp:70,211,230) as one append-only array.
+//   normals:   nv_key u64, nv_slot u32, nv_c/nv_n float3, stats[16] i64 per record (stats.hpp)
+//   dependants: reg_occ (slot, stat id) pairs, append-only; dep[] = 32-byte entries grouped per slot,
+//              rebuilt by every clean pass (VoxelInfo::dependants, grid.hpp:71,417,447).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geometry.hpp"
+
+namespace hfpf {
+
+constexpr uint32_t kLock = 0xFFFFFFFFu;
+constexpr int kBrickShift = 3;
+constexpr int kBrickCells = 512;
+constexpr int kMaxSpin = 1 << 20;
+constexpr uint32_t kNoFrame = 0xFFFFFFFFu;
+
+// info word
+constexpr uint64_t kOcc = 1ull;
+constexpr uint64_t kNormal = 2ull;
+constexpr int kDepCntShift = 2;
+constexpr uint64_t kDepCntMask = 0xFFFFull;
+constexpr int kDepOffShift = 18;
+
+// counters (device u64 array)
+enum Ctr : int {
+    C_BRICKS = 0,   // bricks allocated (ids 1..n)
+    C_LOG,          // point-log entries (1-based indices 1..n)
+    C_OCC,          // entries in occ_list
+    C_NORMALS,      // normal records (ids 1..n)
+    C_REG,          // entries in reg_occ
+    C_DEP,          // entries in dep[]
+    C_PREREG,       // entries in prereg_list
+    C_TOUCHED,      // entries in touched_list (rebuild scratch)
+    C_CAND,         // candidates of the running clean pass
+    C_ERR,          // error bits
+    C_PRESENTED,
+    C_ZPASS,
+    C_INBOX,
+    C_BUFFERED,
+    C_DEP_TESTED,
+    C_DEP_MEMBER,
+    C_ROWS,         // rows valid at extract
+    C_COUNT = 32
+};
+
+enum ErrBits : uint64_t {
+    E_BRICKS = 1,
+    E_LOG = 2,
+    E_OCC = 4,
+    E_NORMALS = 8,
+    E_REG = 16,
+    E_DEP = 32,
+    E_SPIN = 64,
+    E_DEPCNT = 128,
+    E_FRAME = 256,
+};
+
+struct __attribute__((aligned(32))) DepEntry {  // one dependant of a cell, denormalised for the per-point loop
+    uint32_t sid;                               // statistics record to update
+    float cx, cy, cz;                           // its cell centre (getVoxelCenter, grid.hpp:259)
+    float nx, ny, nz;                           // its normal
+    uint32_t pad;
+};
+static_assert(sizeof(DepEntry) == 32, "DepEntry must be 32 bytes");
+
+constexpr int kStatWords = 16;  // i64 words per statistics record (128 B): see stats.hpp
+
+struct Tables {
+    uint32_t* dir;
+    uint32_t* brick_lin;  // [max_bricks+1] linear directory index of brick id
+    uint64_t* info;
+    uint32_t* first_frame;
+    uint32_t* buf_head;
+    uint32_t* stat_id;
+    uint32_t* pre_dep;
+    uint32_t* dep_tmp;
+    uint64_t* occ_mask;
+    float4* log_pt;
+    uint32_t* log_link;
+    uint32_t* occ_list;
+    uint64_t* nv_key;
+    uint32_t* nv_slot;
+    float* nv_c;  // 3 per record
+    float* nv_n;  // 3 per record
+    unsigned long long* stats;
+    uint2* reg_occ;
+    DepEntry* dep;
+    uint32_t* prereg_list;
+    uint32_t* touched_list;
+    uint64_t* cand_key;    // clean scratch (unsorted / sorted ping-pong handled by the host)
+    float* frame_vp;       // 3 per frame id
+    unsigned long long* ctr;
+    uint64_t max_bricks, max_log, max_occ, max_normals, max_reg, max_dep, max_frames;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+HFPF_HD uint64_t make_key(int32_t x, int32_t y, int32_t z) { return ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z; }
+HFPF_HD void key_coords(uint64_t k, int32_t& x, int32_t& y, int32_t& z)
+{
+    x = (int32_t)(k >> 42);
+    y = (int32_t)((k >> 21) & 0x1FFFFF);
+    z = (int32_t)(k & 0x1FFFFF);
+}
+HFPF_HD uint32_t brick_index(const GridParams& g, int32_t x, int32_t y, int32_t z)
+{
+    return ((uint32_t)(x >> kBrickShift) * (uint32_t)g.bdim[1] + (uint32_t)(y >> kBrickShift)) * (uint32_t)g.bdim[2] +
+           (uint32_t)(z >> kBrickShift);
+}
+HFPF_HD uint32_t local_index(int32_t x, int32_t y, int32_t z) { return ((uint32_t)(x & 7) << 6) | ((uint32_t)(y & 7) << 3) | (uint32_t)(z & 7); }
+
+// Cell coordinates of a slot (inverse of the two functions above).
+__device__ __forceinline__ void slot_coords(const GridParams& g, const Tables& t, uint32_t slot, int32_t& x, int32_t& y, int32_t& z)
+{
+    const uint32_t b = slot >> 9, l = slot & 511;
+    const uint32_t lin = t.brick_lin[b];
+    const uint32_t bz = lin % (uint32_t)g.bdim[2];
+    const uint32_t r = lin / (uint32_t)g.bdim[2];
+    const uint32_t by = r % (uint32_t)g.bdim[1];
+    const uint32_t bx = r / (uint32_t)g.bdim[1];
+    x = (int32_t)(bx * 8 + (l >> 6));
+    y = (int32_t)(by * 8 + ((l >> 3) & 7));
+    z = (int32_t)(bz * 8 + (l & 7));
+}
+
+// Read-only lookup: slot of a cell, inside the null brick (all zeros) when the brick was never touched.
+__device__ __forceinline__ uint32_t slot_lookup(const GridParams& g, const Tables& t, int32_t x, int32_t y, int32_t z)
+{
+    uint32_t b = t.dir[brick_index(g, x, y, z)];
+    if (b == kLock) b = 0;  // cannot happen between kernels; defensive
+    return b * kBrickCells + local_index(x, y, z);
+}
+
+// One lane claims (or finds) the brick of directory entry `bidx`.  Lock-free for readers; a writer
+// that loses the CAS waits for the winner's id, which another *wave* is guaranteed to publish (the
+// wave-level election below makes sure two lanes of one wave never wait on each other).  Bounded.
+__device__ inline uint32_t brick_acquire_single(const Tables& t, uint32_t bidx)
+{
+    uint32_t* p = &t.dir[bidx];
+    for (int spin = 0; spin < kMaxSpin; ++spin) {
+        uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0) {
+            const uint32_t old = atomicCAS(p, 0u, kLock);
+            if (old == 0) {
+                const unsigned long long id = atomicAdd(&t.ctr[C_BRICKS], 1ull) + 1ull;
+                if (id > t.max_bricks) {
+                    atomicOr(&t.ctr[C_ERR], (unsigned long long)E_BRICKS);
+                    __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return 0;
+                }
+                t.brick_lin[id] = bidx;
+                __hip_atomic_store(p, (uint32_t)id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return (uint32_t)id;
+            }
+            v = old;
+        }
+        if (v != kLock) return v;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    atomicOr(&t.ctr[C_ERR], (unsigned long long)E_SPIN);
+    return 0;
+}
+
+// Wave-level election: every lane that needs a brick which is not there yet takes part; one lane per
+// distinct directory entry runs the claim, the others receive its id through a shuffle.
+// Must be reached by all 64 lanes of the wave (convergent); `want` masks the lanes with real work.
+__device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bool want)
+{
+    uint32_t v = 0;
+    if (want) v = __hip_atomic_load(&t.dir[bidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool need = want && (v == 0 || v == kLock);
+    unsigned long long m = __ballot(need);
+    const uint32_t lane = lane_id();
+    while (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t lb = __shfl(bidx, leader);
+        uint32_t id = 0;
+        if (lane == (uint32_t)leader) id = brick_acquire_single(t, lb);
+        id = __shfl(id, leader);
+        if (need && bidx == lb) {
+            v = id;
+            need = false;
+        }
+        m = __ballot(need);
+    }
+    return v;
+}
+
+// Wave-aggregated bump allocation: one atomic per wave, ranks by prefix popcount of the ballot.
+// Returns the 0-based index reserved for this lane (meaningless when !want). Convergent.
+__device__ inline unsigned long long wave_reserve(unsigned long long* ctr, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return 0;
+    const uint32_t lane = lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == (uint32_t)leader) base = atomicAdd(ctr, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// Wave-reduced counter add (diagnostic counters): convergent.
+__device__ inline void wave_count(unsigned long long* ctr, uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane_id() == 0 && v) atomicAdd(ctr, (unsigned long long)v);
+}
+
+}  // namespace hfpf

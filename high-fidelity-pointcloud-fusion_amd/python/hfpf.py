@@ -1,0 +1,338 @@
+"""ctypes binding of libhfpf.so (include/hfpf.h) -- the host-side mirror used by tests and bench.py.
+
+`OccupancyGrid` mirrors the public members of the reference's `class OccupancyGrid`
+(pointcloud_fusion/pointcloud_fusion/include/utilities/OccupancyGrid.hpp:99-136) as the node uses them
+(.../src/pointcloud_fusion_and_filter.cpp:161-164,293,311,398,438): construct, addPoints (here `integrate`,
+which also folds in the decode / z-clip / transform of the capture threads), state_changed,
+updateThicknessVectors (`clean`), downloadData (`extract` / `download_data`), clearVoxels (`clear`).
+
+There is no CPU path: constructing a grid raises HfpfError when libhfpf.so is missing or no HIP device
+is usable.  This module never imports the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(_HERE)
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libhfpf.so")
+
+STATUS = {0: "OK", -1: "BAD_CONFIG", -2: "BAD_ARG", -3: "CAPACITY", -4: "HIP", -5: "STATE", -6: "IO", -7: "DIST"}
+
+
+class HfpfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hfpf status %d (%s): %s" % (code, STATUS.get(code, "?"), msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("resolution", C.c_float),
+        ("bbox", C.c_double * 6),
+        ("k", C.c_int32),
+        ("K", C.c_int32),
+        ("gate", C.c_int32),
+        ("cylinder_radius", C.c_double),
+        ("ball_radius", C.c_double),
+        ("z_clip_min", C.c_double),
+        ("z_clip_max", C.c_double),
+        ("device", C.c_int32),
+        ("flags", C.c_uint32),
+        ("max_bricks", C.c_uint64),
+        ("max_log_points", C.c_uint64),
+        ("max_normals", C.c_uint64),
+        ("max_frames", C.c_uint64),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "points_presented", "points_zclip_pass", "points_in_bbox", "points_buffered", "dep_pairs_tested",
+        "dep_pairs_member", "voxels_occupied", "voxels_with_normal", "bricks_allocated", "registrations",
+        "dep_entries", "frames_integrated", "clean_passes", "device_bytes")]
+
+
+ROW_DTYPE = np.dtype(
+    [
+        ("ix", "<i4"), ("iy", "<i4"), ("iz", "<i4"), ("count", "<u4"),
+        ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
+        ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"),
+        ("sdx", "<f4"), ("sdy", "<f4"), ("sdz", "<f4"),
+        ("mean_dist", "<f4"), ("sd_dist", "<f4"), ("rgb", "<u4"),
+    ]
+)
+
+# every symbol include/hfpf.h and include/hfpf_probe.h declare
+EXPORTS = [
+    "hfpf_default_config", "hfpf_abi_version", "hfpf_create", "hfpf_destroy", "hfpf_last_error", "hfpf_get_dims",
+    "hfpf_integrate", "hfpf_integrate_device", "hfpf_is_dirty", "hfpf_clean", "hfpf_extract", "hfpf_free_rows",
+    "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
+    "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
+    "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
+]
+
+
+def build(force=False):
+    """hipcc cross-compiles gfx950 without a GPU; see csrc/Makefile."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", CSRC_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HfpfError(-4, "libhfpf.so not built (%s); run __graft_entry__.build() -- there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    L.hfpf_default_config.argtypes = [C.POINTER(Config)]
+    L.hfpf_default_config.restype = None
+    L.hfpf_abi_version.restype = C.c_int
+    L.hfpf_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.hfpf_destroy.argtypes = [vp]
+    L.hfpf_last_error.argtypes = [vp]
+    L.hfpf_last_error.restype = C.c_char_p
+    L.hfpf_get_dims.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
+    L.hfpf_integrate.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp]
+    L.hfpf_integrate_device.argtypes = [vp, vp, u32, u64, u32, u32, u32, u32, u32, u32, vp, vp]
+    L.hfpf_is_dirty.argtypes = [vp]
+    L.hfpf_clean.argtypes = [vp]
+    L.hfpf_extract.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.hfpf_free_rows.argtypes = [vp]
+    L.hfpf_free_rows.restype = None
+    L.hfpf_write_pcd.argtypes = [vp, u64, C.c_char_p]
+    L.hfpf_write_meta_csv.argtypes = [vp, u64, C.c_char_p]
+    L.hfpf_clear.argtypes = [vp]
+    L.hfpf_sync.argtypes = [vp]
+    L.hfpf_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.hfpf_get_occupied.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.hfpf_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.hfpf_device_free.argtypes = [vp, vp]
+    L.hfpf_device_upload.argtypes = [vp, vp, vp, u64]
+    L.hfpf_kernel_timing.argtypes = [vp, C.c_int]
+    L.hfpf_get_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.hfpf_probe_points.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    L.hfpf_probe_normals.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+    L.hfpf_probe_project.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
+    L.hfpf_probe_trig.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_config():
+    c = Config()
+    lib().hfpf_default_config(C.byref(c))
+    return c
+
+
+class OccupancyGrid:
+    """Device-resident occupancy grid.  Keyword defaults are the reference's constants."""
+
+    def __init__(self, resolution=None, bbox=None, k=None, K=None, gate=None, cylinder_radius=None, ball_radius=None,
+                 z_clip=None, device=0, max_bricks=0, max_log_points=0, max_normals=0, max_frames=0):
+        L = lib()
+        c = default_config()
+        if resolution is not None:
+            c.resolution = resolution
+        if bbox is not None:
+            if len(bbox) != 6:
+                raise HfpfError(-1, "bounding_box needs 6 values (xmin,xmax,ymin,ymax,zmin,zmax)")
+            for i in range(6):
+                c.bbox[i] = float(bbox[i])
+        for name, val in (("k", k), ("K", K), ("gate", gate), ("cylinder_radius", cylinder_radius),
+                          ("ball_radius", ball_radius)):
+            if val is not None:
+                setattr(c, name, val)
+        if z_clip is not None:
+            c.z_clip_min, c.z_clip_max = z_clip
+        c.device = device
+        c.max_bricks, c.max_log_points, c.max_normals, c.max_frames = max_bricks, max_log_points, max_normals, max_frames
+        self.cfg = c
+        self._h = C.c_void_p()
+        rc = L.hfpf_create(C.byref(c), C.byref(self._h))
+        if rc != 0:
+            msg = L.hfpf_last_error(None).decode()
+            self._h = None
+            raise HfpfError(rc, msg)
+
+    # -- plumbing --
+    def _chk(self, rc):
+        if rc < 0:
+            raise HfpfError(rc, lib().hfpf_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hfpf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def dims(self):
+        d = (C.c_int32 * 3)()
+        r = C.c_double()
+        self._chk(lib().hfpf_get_dims(self._h, d, C.byref(r)))
+        return (d[0], d[1], d[2]), r.value
+
+    # -- the reference surface --
+    def integrate(self, buf, pose, n_points=None, point_step=16, off_x=0, off_y=4, off_z=8, off_rgb=12):
+        """addPoints + capture stage for one host frame (PointCloud2-style records)."""
+        buf = np.ascontiguousarray(buf)
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        if n_points is None:
+            n_points = buf.nbytes // point_step
+        self._chk(lib().hfpf_integrate(self._h, _p(buf), n_points, point_step, off_x, off_y, off_z, off_rgb, _p(pose)))
+
+    def integrate_device(self, dev_ptr, n_frames, frame_stride, n_points, poses, frame_ids=None, point_step=16, off_x=0,
+                         off_y=4, off_z=8, off_rgb=12):
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(n_frames, 12)
+        ids = None
+        if frame_ids is not None:
+            ids = np.ascontiguousarray(frame_ids, dtype=np.uint32)
+        self._chk(lib().hfpf_integrate_device(self._h, C.c_void_p(dev_ptr), n_frames, frame_stride, n_points, point_step,
+                                              off_x, off_y, off_z, off_rgb, _p(poses), _p(ids) if ids is not None else None))
+
+    @property
+    def state_changed(self):
+        return bool(self._chk(lib().hfpf_is_dirty(self._h)))
+
+    def clean(self):
+        self._chk(lib().hfpf_clean(self._h))
+
+    def extract(self):
+        rows = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(lib().hfpf_extract(self._h, C.byref(rows), C.byref(n)))
+        out = np.zeros(n.value, dtype=ROW_DTYPE)
+        if n.value:
+            C.memmove(out.ctypes.data, rows.value, n.value * ROW_DTYPE.itemsize)
+            lib().hfpf_free_rows(rows)
+        return out
+
+    def download_data(self, cloud_location, metadata):
+        """downloadData(cloud_location, metadata): writes test_cloud.pcd and meta.csv; returns the rows."""
+        rows = self.extract()
+        write_pcd(rows, cloud_location)
+        write_meta_csv(rows, metadata)
+        return rows
+
+    def clear(self):
+        self._chk(lib().hfpf_clear(self._h))
+
+    # -- diagnostics / harness --
+    def sync(self):
+        self._chk(lib().hfpf_sync(self._h))
+
+    def counters(self):
+        c = Counters()
+        self._chk(lib().hfpf_get_counters(self._h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def occupied(self):
+        n = C.c_uint64()
+        self._chk(lib().hfpf_get_occupied(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3), dtype=np.int32)
+        if n.value:
+            self._chk(lib().hfpf_get_occupied(self._h, _p(out), n.value, C.byref(n)))
+        return out
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(lib().hfpf_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr):
+        self._chk(lib().hfpf_device_free(self._h, C.c_void_p(ptr)))
+
+    def device_upload(self, dev_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(lib().hfpf_device_upload(self._h, C.c_void_p(dev_ptr), _p(arr), arr.nbytes))
+
+    def kernel_timing(self, enable=True):
+        self._chk(lib().hfpf_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_time(self, kernel_id=0):
+        ms = C.c_double()
+        n = C.c_uint64()
+        self._chk(lib().hfpf_get_kernel_time(self._h, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- leaf probes (tests) --
+    def probe_points(self, pose, xyz):
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        n = xyz.shape[0]
+        q = np.zeros((n, 3), np.float32)
+        idx = np.zeros((n, 3), np.int32)
+        flags = np.zeros(n, np.uint8)
+        self._chk(lib().hfpf_probe_points(self._h, _p(pose), _p(xyz), n, _p(q), _p(idx), _p(flags)))
+        return q, idx, flags
+
+    def probe_normals(self, cells, occ, vps):
+        cells = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        n = cells.shape[0]
+        occ = np.ascontiguousarray(occ, dtype=np.uint8).reshape(n, 125)
+        vps = np.ascontiguousarray(vps, dtype=np.float32).reshape(n, 3)
+        normals = np.zeros((n, 3), np.float32)
+        totals = np.zeros(n, np.int32)
+        self._chk(lib().hfpf_probe_normals(self._h, n, _p(cells), _p(occ), _p(vps), _p(normals), _p(totals)))
+        return normals, totals
+
+    def probe_project(self, pts, centres, normals):
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+        n = pts.shape[0]
+        centres = np.ascontiguousarray(centres, dtype=np.float32).reshape(n, 3)
+        normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(n, 3)
+        proj = np.zeros((n, 3), np.float32)
+        dist = np.zeros(n, np.float64)
+        member = np.zeros(n, np.uint8)
+        self._chk(lib().hfpf_probe_project(self._h, n, _p(pts), _p(centres), _p(normals), _p(proj), _p(dist), _p(member)))
+        return proj, dist, member.astype(bool)
+
+    def probe_trig(self, y, x):
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        a = np.zeros_like(x)
+        c = np.zeros_like(x)
+        s = np.zeros_like(x)
+        self._chk(lib().hfpf_probe_trig(self._h, x.size, _p(y), _p(x), _p(a), _p(c), _p(s)))
+        return a, c, s
+
+
+def write_pcd(rows, path):
+    rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    rc = lib().hfpf_write_pcd(_p(rows), rows.size, os.fsencode(path))
+    if rc != 0:
+        raise HfpfError(rc, "write_pcd(%s)" % path)
+
+
+def write_meta_csv(rows, path):
+    rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    rc = lib().hfpf_write_meta_csv(_p(rows), rows.size, os.fsencode(path))
+    if rc != 0:
+        raise HfpfError(rc, "write_meta_csv(%s)" % path)

@@ -1,0 +1,164 @@
+/* include/hfpf.h -- C ABI of the MI355X-native occupancy-grid point-cloud fusion engine (libhfpf.so).
+ *
+ * This is the drop-in boundary for the reference's `class OccupancyGrid`
+ * (pointcloud_fusion/pointcloud_fusion/include/utilities/OccupancyGrid.hpp:99-136, "grid.hpp" below),
+ * which the reference node owns by value as `PointcloudFusion::grid_`
+ * (pointcloud_fusion/pointcloud_fusion/src/pointcloud_fusion_and_filter.cpp:132, "node.cpp" below).
+ * The reference has no FFI layer of its own; each entry point cites the member function / call site
+ * it replaces.  Plain pointers and sizes only; no C++ or torch types cross this boundary; nothing
+ * throws across it.  All functions return an hfpf_status (0 = ok, negative = error) unless noted,
+ * and may be called from any thread (the handle serialises mutating calls internally; the reference
+ * serialises with grid_mtx_, node.cpp:142,291,305).
+ *
+ * The engine has no CPU fallback: every entry point that computes runs HIP kernels on the
+ * configured device and fails with HFPF_ERR_HIP when no device is usable.
+ */
+#ifndef HFPF_H
+#define HFPF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFPF_ABI_VERSION 1
+
+typedef struct hfpf_handle hfpf_handle;
+
+typedef enum hfpf_status {
+    HFPF_OK = 0,
+    HFPF_ERR_BAD_CONFIG = -1, /* bbox max<=min, resolution<=0, k!=2, K out of range ... */
+    HFPF_ERR_BAD_ARG = -2,
+    HFPF_ERR_CAPACITY = -3, /* a device pool (bricks, point log, normals, registrations) overflowed */
+    HFPF_ERR_HIP = -4,      /* HIP runtime error; see hfpf_last_error */
+    HFPF_ERR_STATE = -5,
+    HFPF_ERR_IO = -6,
+    HFPF_ERR_DIST = -7 /* RCCL / rank bootstrap error */
+} hfpf_status;
+
+/* Replaces setResolution/setDimensions/setK/construct (grid.hpp:614,604,138,621; called once from
+ * the node ctor, node.cpp:161-164) plus the compile-time constants of the capture stage.
+ * Defaults (hfpf_default_config) are the reference's values. */
+typedef struct hfpf_config {
+    uint32_t struct_size;     /* = sizeof(hfpf_config) */
+    float resolution;         /* voxel edge, metres, AS FLOAT: the reference stores a float into a double
+                                 member (grid.hpp:614-619), so 0.005f -> 0.004999999888241291. node.cpp:91 */
+    double bbox[6];           /* xmin,xmax,ymin,ymax,zmin,zmax; launch param `bounding_box` (node.cpp:451,162) */
+    int32_t k;                /* occupancy stencil half-width; must be 2 (grid.hpp:334 hard-codes 125 probes) */
+    int32_t K;                /* line half-length in voxel steps (template arg, node.cpp:311,317) = 3 */
+    int32_t gate;             /* a voxel gets a normal when occupied neighbours > gate (grid.hpp:352) = 20 */
+    double cylinder_radius;   /* kCylinderRadius, grid.hpp:36 = 0.001 */
+    double ball_radius;       /* kBballRadius, grid.hpp:35 = 0.015 */
+    double z_clip_min;        /* kZmin, node.cpp:92 = 0.28 (camera frame, strict) */
+    double z_clip_max;        /* kZmax, node.cpp:93 = 0.6 */
+    int32_t device;           /* HIP device ordinal */
+    uint32_t flags;           /* reserved, 0 */
+    /* Device pool capacities; 0 = engine default.  The reference grows without bound (README:12). */
+    uint64_t max_bricks;      /* 8x8x8-voxel bricks that may be touched */
+    uint64_t max_log_points;  /* points buffered while their voxel has no normal (grid.hpp:211,230) */
+    uint64_t max_normals;     /* voxels that may receive a normal */
+    uint64_t max_frames;      /* frame ids (viewpoint table) */
+} hfpf_config;
+
+/* One emitted voxel = one line of test_cloud.pcd + one line of meta.csv (grid.hpp:466-480). 64 bytes. */
+typedef struct hfpf_row {
+    int32_t ix, iy, iz;  /* voxel index triplet */
+    uint32_t count;      /* points in cylinder (VoxelInfo::count) */
+    float x, y, z;       /* cylinder-filtered mean of projected points (VoxelInfo::centroid); (0,0,0) when count==0 */
+    float nx, ny, nz;    /* VoxelInfo::normal */
+    float sdx, sdy, sdz; /* VoxelInfo::sd (population variance per axis, as the reference's Welford recurrence) */
+    float mean_dist;     /* VoxelInfo::mean_dist */
+    float sd_dist;       /* VoxelInfo::sd_dist */
+    uint32_t rgb;        /* EXTENSION: mean colour of the cylinder members, 0x00RRGGBB (the reference never writes rgb) */
+} hfpf_row;
+
+typedef struct hfpf_counters {
+    uint64_t points_presented;  /* input points seen by integrate (before any clip) */
+    uint64_t points_zclip_pass; /* survived the camera-frame z-clip */
+    uint64_t points_in_bbox;    /* survived the bbox clip (= voxel touches) */
+    uint64_t points_buffered;   /* appended to the point log */
+    uint64_t dep_pairs_tested;  /* (point, dependant) cylinder tests in integrate */
+    uint64_t dep_pairs_member;  /* ... that were inside the cylinder */
+    uint64_t voxels_occupied;
+    uint64_t voxels_with_normal;
+    uint64_t bricks_allocated;
+    uint64_t registrations;     /* dependant registrations on occupied cells (grid.hpp:417) */
+    uint64_t dep_entries;       /* entries in the current dependant table */
+    uint64_t frames_integrated;
+    uint64_t clean_passes;
+    uint64_t device_bytes;      /* HBM allocated by this handle */
+} hfpf_counters;
+
+void hfpf_default_config(hfpf_config* cfg);
+int hfpf_abi_version(void);
+
+/* OccupancyGrid(), setResolution, setDimensions, setK, construct  (grid.hpp:111,614,604,138,621). */
+int hfpf_create(const hfpf_config* cfg, hfpf_handle** out);
+/* The reference never destroys its grid (no destructor; leaks). */
+int hfpf_destroy(hfpf_handle* h);
+/* Thread-local-free: the last error text of this handle (or of create when h == NULL). */
+const char* hfpf_last_error(const hfpf_handle* h);
+/* xdim,ydim,zdim as construct() truncates them (grid.hpp:623-625) and the resolution as a double. */
+int hfpf_get_dims(const hfpf_handle* h, int32_t dims[3], double* resolution);
+
+/* Integrate one frame given as PointCloud2-style records in HOST memory.
+ * Replaces, in one call: pointCloud2ToPclXYZRGBOMP (node.cpp:182-216), the z-clip (node.cpp:251-255),
+ * pcl::transformPointCloud (node.cpp:289), the viewpoint (node.cpp:290) and
+ * OccupancyGrid::addPoints<N> (grid.hpp:185-280; call sites node.cpp:293,295).
+ *   base        first record; n_points records of point_step bytes.  The caller applies the
+ *               reference's first-row rule, i.e. n_points = row_step / point_step (node.cpp:185,190).
+ *   off_*       byte offsets of the f32 fields x,y,z,rgb inside a record (fields[0..3].offset).
+ *   pose_3x4    fusion_frame <- camera, row-major 3x4 f64 (the Affine3d of node.cpp:338).
+ * The buffer is copied before the call returns.  Frame ids count up from 0 per handle. */
+int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x,
+                   uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double pose_3x4[12]);
+
+/* Same path for frames already resident in HBM: n_frames frames, frame f at dev_base + f*frame_stride,
+ * poses = n_frames*12 f64 in HOST memory, frame_ids = n_frames ids in HOST memory or NULL (auto).
+ * One launch covers the whole batch; asynchronous on the engine's stream. */
+int hfpf_integrate_device(hfpf_handle* h, const void* dev_base, uint32_t n_frames, uint64_t frame_stride,
+                          uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                          uint32_t off_rgb, const double* poses, const uint32_t* frame_ids);
+
+/* OccupancyGrid::state_changed (grid.hpp:110; read at node.cpp:306). Returns 0/1, or a negative status. */
+int hfpf_is_dirty(hfpf_handle* h);
+/* OccupancyGrid::updateThicknessVectors<N,K> (grid.hpp:311-454; call sites node.cpp:311,317).
+ * Candidates are processed in canonical ascending (x,y,z) order. */
+int hfpf_clean(hfpf_handle* h);
+
+/* OccupancyGrid::downloadData (grid.hpp:456-488; call site node.cpp:398) split in two: the ordered
+ * extract (rows in lexicographic x,y,z order, engine-owned buffer) and the two file writers. */
+int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows);
+void hfpf_free_rows(hfpf_row* rows);
+/* <directory_name>/test_cloud.pcd (node.cpp:395): PCD v0.7 ASCII, FIELDS x y z rgb normal_x normal_y normal_z curvature */
+int hfpf_write_pcd(const hfpf_row* rows, uint64_t n_rows, const char* path);
+/* <directory_name>/meta.csv (node.cpp:396) with the header string of grid.hpp:462 */
+int hfpf_write_meta_csv(const hfpf_row* rows, uint64_t n_rows, const char* path);
+
+/* OccupancyGrid::clearVoxels (grid.hpp:167-183; call site node.cpp:438).  Full reset (documented
+ * deviation: the reference leaves stale keys and dependants-only blocks behind). */
+int hfpf_clear(hfpf_handle* h);
+
+/* Wait for all queued work of this handle; surfaces deferred capacity/HIP errors. */
+int hfpf_sync(hfpf_handle* h);
+int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out);
+
+/* Occupied voxel triplets in ascending (x,y,z) order (test/diagnostic: bit-exact occupancy parity).
+ * xyz may be NULL to query the count; at most cap triplets are written. */
+int hfpf_get_occupied(hfpf_handle* h, int32_t* xyz, uint64_t cap, uint64_t* n_out);
+
+/* ---- harness helpers (device staging without any framework) ---- */
+int hfpf_device_alloc(hfpf_handle* h, uint64_t bytes, void** dev_ptr);
+int hfpf_device_free(hfpf_handle* h, void* dev_ptr);
+int hfpf_device_upload(hfpf_handle* h, void* dev_dst, const void* host_src, uint64_t bytes);
+
+/* ---- measurement: HIP-event timing of the engine's own kernels on the engine's stream ----
+ * kernel ids: 0 = integrate.  total_ms / launches accumulate since enable. */
+int hfpf_kernel_timing(hfpf_handle* h, int enable);
+int hfpf_get_kernel_time(hfpf_handle* h, int kernel_id, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFPF_H */

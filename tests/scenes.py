@@ -1,0 +1,74 @@
+"""Shared scene / schedule helpers for the parity tests (imported by tests only)."""
+import numpy as np
+
+import hfpf_synth as S
+
+BBOX_1M = (-0.5, 0.5, -0.5, 0.5, 0.0, 1.0)
+
+
+class Scene:
+    """A seeded synthetic stream: frames (camera-frame XYZRGB records) + poses + a clean schedule."""
+
+    def __init__(self, n_frames, W, H, resolution, bbox=BBOX_1M, fx=0.0, seed=0xF051, pose_seed=0x5E3, clean_every=0,
+                 identity=False, layout=None, max_angle=30.0, jitter=0.05, noise=0.0005, nan_permille=20):
+        self.n_frames, self.W, self.H = n_frames, W, H
+        self.resolution, self.bbox, self.fx = resolution, bbox, fx
+        self.seed, self.pose_seed = seed, pose_seed
+        self.clean_every = clean_every
+        self.layout = layout or S.LAYOUT_PACKED16
+        self.poses = [S.identity_pose() if identity else S.pose(pose_seed, f, max_angle, jitter) for f in range(n_frames)]
+        self.noise, self.nan_permille = noise, nan_permille
+
+    def frame(self, f):
+        return S.frame(self.seed, f, self.W, self.H, self.poses[f], noise_sigma=self.noise, nan_permille=self.nan_permille,
+                       fx=self.fx, layout=self.layout)
+
+    def schedule(self):
+        """Yields ('integrate', f) / ('clean',) events; always ends with a clean (explicit schedule)."""
+        for f in range(self.n_frames):
+            yield ("integrate", f)
+            if self.clean_every and (f + 1) % self.clean_every == 0 and f + 1 < self.n_frames:
+                yield ("clean",)
+        yield ("clean",)
+
+
+def run(grid, scene, capture_name):
+    """Drive an oracle grid (capture) or an engine grid (integrate) through the scene's schedule."""
+    lay = scene.layout
+    for ev in scene.schedule():
+        if ev[0] == "integrate":
+            buf = scene.frame(ev[1])
+            kw = dict(point_step=lay["point_step"], off_x=lay["off_x"], off_y=lay["off_y"], off_z=lay["off_z"])
+            if capture_name == "integrate":
+                kw["off_rgb"] = lay["off_rgb"]
+            getattr(grid, capture_name)(buf, scene.poses[ev[1]], **kw)
+        else:
+            grid.clean()
+    return grid.extract()
+
+
+XYZ_TOL = 1e-5  # north_star: fused XYZ within 1e-5
+
+
+def compare_rows(ref, got, normals_exact=True):
+    """ref = oracle rows, got = engine rows.  Integer work bit-exact; XYZ within 1e-5 (north_star)."""
+    assert len(ref) == len(got), "row count %d != %d" % (len(ref), len(got))
+    for f in ("ix", "iy", "iz"):
+        assert np.array_equal(ref[f], got[f]), "voxel index column %s differs" % f
+    assert np.array_equal(ref["count"], got["count"]), "points-in-cylinder counts differ at %d rows" % int(
+        np.sum(ref["count"] != got["count"]))
+    for f in ("nx", "ny", "nz"):
+        if normals_exact:
+            assert np.array_equal(ref[f].view(np.uint32), got[f].view(np.uint32)), "normal %s not bit-identical" % f
+        else:
+            assert np.allclose(ref[f], got[f], atol=1e-5, rtol=0)
+    for f in ("x", "y", "z"):
+        d = np.abs(ref[f].astype(np.float64) - got[f].astype(np.float64))
+        assert d.max(initial=0.0) <= XYZ_TOL, "fused %s differs by %.3g" % (f, d.max())
+    # meta.csv columns: the reference prints 6 significant digits of float Welford recurrences whose own
+    # rounding noise is ~1e-4 relative; compare loosely (documented in DESIGN.md).
+    for f in ("mean_dist",):
+        assert np.allclose(ref[f], got[f], rtol=1e-4, atol=1e-9), f
+    for f in ("sdx", "sdy", "sdz", "sd_dist"):
+        assert np.allclose(ref[f], got[f], rtol=5e-2, atol=2e-10), "%s max abs diff %.3g" % (
+            f, np.abs(ref[f].astype(np.float64) - got[f]).max(initial=0.0))
