@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mpts/s fused into a 1 mm voxel grid (BASELINE.json).
+
+A "step" is one 640x480 synthetic organised XYZRGB frame (307,200 points, published height=1) pushed
+through the hot path: decode + z-clip + SE(3) + bbox clip + voxel insert/append + dependant updates, with a
+clean pass every --clean-every frames and a final clean, all inside the timed region.  Frames are
+pre-staged in HBM before the clock starts (configs[1] of BASELINE.json: 1000-frame stream, random SE(3)
+poses, 1 m^3 bbox @ 1 mm on one MI355X).  Extract is timed separately and reported as `extract_s`.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N>1 the driver launches one rank per GPU with torch.distributed.run; every rank fuses its own K-frame
+camera stream (weak scaling) and the engine merges occupancy / statistics over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "high-fidelity-pointcloud-fusion_amd")
+sys.path.insert(0, os.path.join(PKG, "python"))
+
+import numpy as np  # noqa: E402
+
+import hfpf  # noqa: E402
+import hfpf_synth as S  # noqa: E402
+
+W, H = 640, 480
+NPTS = W * H
+POINT_STEP = 16
+BBOX = (-0.5, 0.5, -0.5, 0.5, 0.0, 1.0)
+RES = 0.001
+ALGO_BYTES_PER_POINT = 32  # 16 B point read + 16 B voxel-record touch
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_stream(seed, pose_seed, n_frames):
+    poses = np.stack([S.pose(pose_seed, f, 30.0, 0.05) for f in range(n_frames)]).reshape(n_frames, 12)
+    return poses
+
+
+def cpu_baseline(poses, seed, n_sample, clean_every):
+    """The CPU oracle (kind "port": the reference itself cannot be built here) timed single-threaded on the
+    first n_sample frames of the same stream, with the same clean cadence and a final clean."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # only the cpu_baseline leg touches the oracle
+
+    og = oracle.OracleGrid(resolution=RES, bbox=BBOX)
+    frames = [S.frame(seed, f, W, H, poses[f].reshape(3, 4)) for f in range(n_sample)]
+    t0 = time.perf_counter()
+    for f in range(n_sample):
+        og.capture(frames[f], poses[f])
+        if clean_every and (f + 1) % clean_every == 0 and f + 1 < n_sample:
+            og.clean()
+    og.clean()
+    dt = time.perf_counter() - t0
+    og.close()
+    return {"value": round(n_sample * NPTS / dt / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
+            "sample": "first %d frames of the same stream + final clean, single thread, sparse oracle (%.1f s)" % (n_sample, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--clean-every", type=int, default=150)
+    ap.add_argument("--frames-per-call", type=int, default=50)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--host-path-frames", type=int, default=20, help="frames also pushed through the host-buffer entry point")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rank bootstrap + barriers only; the data path is the engine's own RCCL
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    K, Wm = args.steps, args.warmup
+    seed = 0xF051 + 7919 * rank  # one camera stream per GPU (BASELINE configs[3] style sharding)
+    pose_seed = 0x5E3 + 104729 * rank
+    n_gen = max(K, Wm)
+    poses = make_stream(seed, pose_seed, n_gen)
+
+    grid = hfpf.OccupancyGrid(resolution=RES, bbox=BBOX, device=local_rank, max_bricks=400000,
+                              max_log_points=min(max(n_gen, 64) * NPTS, 1 << 31), max_normals=24 << 20,
+                              max_frames=max(n_gen * max(world, 1) + 16, 4096))
+    if world > 1:
+        grid.dist_init(rank, world, dist)
+
+    # ---- stage frames in HBM (not timed) ----
+    t_gen = time.perf_counter()
+    frame_bytes = NPTS * POINT_STEP
+    dev = grid.device_alloc(n_gen * frame_bytes)
+    buf = np.empty(frame_bytes, dtype=np.uint8)
+    host_frames = []
+    for f in range(n_gen):
+        S.frame(seed, f, W, H, poses[f].reshape(3, 4), out=buf)
+        grid.device_upload(dev + f * frame_bytes, buf)
+        if f < args.host_path_frames:
+            host_frames.append(buf.copy())
+    log("rank %d: staged %d frames (%.2f GB) in %.1f s" % (rank, n_gen, n_gen * frame_bytes / 1e9, time.perf_counter() - t_gen))
+
+    def run_stream(n_frames, timed):
+        done = 0
+        B = max(1, args.frames_per_call)
+        while done < n_frames:
+            nxt = n_frames
+            if args.clean_every:
+                nxt = min(nxt, (done // args.clean_every + 1) * args.clean_every)
+            b = min(B, nxt - done)
+            ids = (np.arange(done, done + b, dtype=np.uint32) * world + rank).astype(np.uint32)
+            grid.integrate_device(dev + done * frame_bytes, b, frame_bytes, NPTS, poses[done:done + b], frame_ids=ids)
+            done += b
+            if args.clean_every and done % args.clean_every == 0 and done < n_frames:
+                grid.clean()
+        grid.clean()
+
+    # ---- warmup (untimed), then reset ----
+    if Wm > 0:
+        run_stream(Wm, False)
+        grid.sync()
+    grid.clear()
+    grid.sync()
+
+    # ---- timed region: exactly K steps ----
+    grid.kernel_timing(True)
+    if dist is not None:
+        dist.barrier()
+    grid.sync()
+    t0 = time.perf_counter()
+    run_stream(K, True)
+    grid.sync()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    k_ms, k_launches = grid.kernel_time(0)
+    grid.kernel_timing(False)
+    ctr = grid.counters()
+
+    # ---- extract (timed separately) ----
+    t2 = time.perf_counter()
+    rows = grid.extract()
+    t3 = time.perf_counter()
+    extract_s = t3 - t2
+
+    # ---- host-buffer entry point (PCIe-inclusive), informational ----
+    host_mpts = None
+    if rank == 0 and host_frames:
+        grid.clear()
+        grid.sync()
+        th = time.perf_counter()
+        for f, hb in enumerate(host_frames):
+            grid.integrate(hb, poses[f])
+        grid.sync()
+        host_mpts = len(host_frames) * NPTS / (time.perf_counter() - th) / 1e6
+
+    total_pts = K * NPTS * world
+    value = total_pts / elapsed / 1e6
+    if rank == 0:
+        pts_per_launch = (K * NPTS) / max(k_launches, 1)
+        avg_launch_s = (k_ms / 1e3) / max(k_launches, 1)
+        achieved = ALGO_BYTES_PER_POINT * pts_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "Mpts/s fused into 1 mm voxel grid",
+            "value": round(value, 3),
+            "unit": "Mpts/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": round(elapsed * 1e3 / K, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 index/transform, f32 geometry, i64 fixed-point sums",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d-frame synthetic 640x480 stream, random SE(3) poses, 1 m^3 bbox @ 1 mm, "
+                                   "clean every %d frames + final clean" % (K, args.clean_every),
+                       "points_per_step": NPTS, "frames_per_call": args.frames_per_call, "parallelism": "frames sharded, %d rank(s)" % world},
+            "extract_s": round(extract_s, 5),
+            "rows_extracted": int(len(rows)),
+            "integrate_kernel_mpts": round(K * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,
+            "host_path_mpts": round(host_mpts, 3) if host_mpts else None,
+            "counters": {k: int(v) for k, v in ctr.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT, "launches": int(k_launches),
+                         "avg_launch_ms": round(avg_launch_s * 1e3, 5)},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen), args.clean_every)
+        print(json.dumps(out), flush=True)
+    grid.device_free(dev)
+    grid.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

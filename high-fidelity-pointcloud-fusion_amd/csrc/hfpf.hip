@@ -74,7 +74,9 @@ struct hfpf_handle {
 
     // host mirrors
     bool dirty = false;
-    uint64_t n_linked = 0;  // log entries already chained
+    uint64_t n_linked[kLogRegions] = {0};  // per log region: entries already chained
+    unsigned long long* h_log_ctr = nullptr;  // pinned mirror of the region counters
+    int integrate_grid = 1536;
     uint64_t frames_integrated = 0;
     uint64_t clean_passes = 0;
     uint32_t next_frame_id = 0;
@@ -153,7 +155,11 @@ __global__ void k_set_ctr(unsigned long long* ctr, int idx, unsigned long long v
 int read_counters(hfpf_handle* h)
 {
     HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->t.ctr, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_log_ctr, h->t.log_ctr, kLogRegions * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned long long total = 0;
+    for (int r = 0; r < kLogRegions; r++) total += std::min<unsigned long long>(h->h_log_ctr[r * 16], h->t.log_region_cap);
+    h->h_ctr[C_LOG] = total;
     return HFPF_OK;
 }
 
@@ -226,8 +232,9 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.occ_mask, 0, (t.max_bricks + 1) * 8 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.stats, 0, (t.max_normals + 1) * kStatWords * 8, s));
     HIPCHK(h, hipMemsetAsync(t.ctr, 0, C_COUNT * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.log_ctr, 0, kLogRegions * 16 * 8, s));
     h->dirty = false;
-    h->n_linked = 0;
+    for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
     h->next_frame_id = 0;
     return HFPF_OK;
 }
@@ -242,6 +249,7 @@ int alloc_tables(hfpf_handle* h)
     if (c.max_normals == 0) c.max_normals = 8ull << 20;
     if (c.max_frames == 0) c.max_frames = 65536;
     if (c.max_bricks > 8388606ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_bricks must be < 2^23");
+    c.max_log_points = std::max<uint64_t>(c.max_log_points, 64 * kLogRegions);
     if (c.max_log_points > 4294967294ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_log_points must be < 2^32-1");
     if (c.max_normals > 4294967294ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_normals must be < 2^32-1");
     t.max_bricks = c.max_bricks;
@@ -280,7 +288,9 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(cand_key, t.max_occ, 0, false);
     ALLOC(frame_vp, 3 * t.max_frames);
     ALLOC(ctr, C_COUNT);
+    ALLOC(log_ctr, kLogRegions * 16);
 #undef ALLOC
+    t.log_region_cap = t.max_log / kLogRegions;
     return reset_state(h);
 }
 
@@ -361,7 +371,8 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     const bool packed = point_step == 16 && off_x == 0 && off_y == 4 && off_z == 8 && off_rgb == 12 && ((uintptr_t)dev_base & 15) == 0 &&
                         (frame_stride & 15) == 0;
     const dim3 block(256);
-    const dim3 grid(std::min<unsigned>(blocks_for(n_points, 256), 4096u), n_frames);
+    const uint64_t n_tiles = (uint64_t)blocks_for(n_points, 256) * n_frames;
+    const dim3 grid((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)h->integrate_grid));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         auto get = [&](hipEvent_t& e) -> hipError_t {
@@ -377,10 +388,10 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
     if (packed)
-        hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, lay,
+        hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay,
                            (const double*)s->d_pose, (const uint32_t*)s->d_ids);
     else
-        hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, lay,
+        hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay,
                            (const double*)s->d_pose, (const uint32_t*)s->d_ids);
     HIPCHK(h, hipGetLastError());
     if (h->timing) {
@@ -417,17 +428,26 @@ int clean_locked(hfpf_handle* h)
     int rc = read_counters(h);
     if (rc) return rc;
     if ((rc = check_device_errors(h))) return rc;
-    const uint64_t n_log = std::min<uint64_t>(h->h_ctr[C_LOG], t.max_log);
     const uint64_t n_occ = std::min<uint64_t>(h->h_ctr[C_OCC], t.max_occ);
     const uint64_t n_normals = h->h_ctr[C_NORMALS];
     h->dirty = false;  // state_changed = false, grid.hpp:313
     h->clean_passes++;
 
-    if (n_log > h->n_linked) {
-        const uint64_t cnt = n_log - h->n_linked;
-        hipLaunchKernelGGL(k_link_log, dim3(blocks_for(cnt, 256)), dim3(256), 0, s, t, (uint32_t)(h->n_linked + 1), (uint32_t)n_log);
-        HIPCHK(h, hipGetLastError());
-        h->n_linked = n_log;
+    {
+        LinkRanges lr;
+        uint64_t max_new = 0;
+        for (int r = 0; r < kLogRegions; r++) {
+            const uint64_t n_r = std::min<uint64_t>(h->h_log_ctr[r * 16], t.log_region_cap);
+            const uint64_t base = (uint64_t)r * t.log_region_cap;
+            lr.first[r] = (uint32_t)(base + h->n_linked[r] + 1);
+            lr.last[r] = (uint32_t)(base + n_r);
+            max_new = std::max(max_new, n_r - h->n_linked[r]);
+            h->n_linked[r] = n_r;
+        }
+        if (max_new) {
+            hipLaunchKernelGGL(k_link_log, dim3(blocks_for(max_new, 256), kLogRegions), dim3(256), 0, s, t, lr);
+            HIPCHK(h, hipGetLastError());
+        }
     }
     if (n_occ == 0) return HFPF_OK;
 
@@ -509,6 +529,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         g_create_error = h->err;
         for (void* p : h->allocs) (void)hipFree(p);
         if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+        if (h->h_log_ctr) (void)hipHostFree(h->h_log_ctr);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         delete h;
         return rc;
@@ -524,6 +545,16 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
     if ((e = hipHostMalloc((void**)&h->h_ctr, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail(fail(h, HFPF_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)));
     memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));
+    if ((e = hipHostMalloc((void**)&h->h_log_ctr, kLogRegions * 16 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+        return bail(fail(h, HFPF_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)));
+    memset(h->h_log_ctr, 0, kLogRegions * 16 * sizeof(unsigned long long));
+    {
+        int per_cu = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate<true>, 256, 0) != hipSuccess) per_cu = 4;
+        h->integrate_grid = std::max(1, per_cu) * std::max(1, cus);
+    }
     if ((rc = alloc_tables(h))) return bail(rc);
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "sync after init: %s", hipGetErrorString(e)));
     *out = h;
@@ -557,6 +588,7 @@ int hfpf_destroy(hfpf_handle* h)
     }
     for (auto e : h->ev_free) (void)hipEventDestroy(e);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+    if (h->h_log_ctr) (void)hipHostFree(h->h_log_ctr);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return HFPF_OK;
@@ -740,7 +772,7 @@ int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)
     out->points_presented = c[C_PRESENTED];
     out->points_zclip_pass = c[C_ZPASS];
     out->points_in_bbox = c[C_INBOX];
-    out->points_buffered = c[C_BUFFERED];
+    out->points_buffered = c[C_LOG];
     out->dep_pairs_tested = c[C_DEP_TESTED];
     out->dep_pairs_member = c[C_DEP_MEMBER];
     out->voxels_occupied = c[C_OCC];

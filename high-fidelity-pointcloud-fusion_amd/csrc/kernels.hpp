@@ -17,34 +17,55 @@ struct FrameLayout {
 };
 
 // ------------------------------------------------------------------------------------------------
-// K1: one thread per input point, grid.y = frame of the batch.  Loop trip counts are wave-uniform so
-// the ballot/shuffle helpers stay convergent.
+// K1.  Persistent grid: block b walks tiles b, b+gridDim.x, ... of 256 consecutive points; a tile never
+// straddles two frames, so the pose stays in scalar registers.  Loop trip counts are wave-uniform, which
+// keeps the ballot/shuffle helpers convergent.
+//
+// Hot-counter discipline: one same-address device atomic costs ~12 ns at the memory side whatever the
+// issuer (MI355X_MICROARCH.md "fanin"), so diagnostics stay in registers until the block retires and the
+// point log is striped over kLogRegions append regions with one counter per 128-byte line.
+//
+// Dependant updates: every (point, dependant) pair that falls inside the 1 mm cylinder adds 12 int64
+// words to ONE 128-byte statistics record.  A lane-per-pair loop would issue 12 fully scattered atomic
+// instructions per round (64 lanes x 12 = 768 memory-side requests); instead the member lanes park their
+// deltas in a per-wave LDS queue and the wave replays the queue with 16 lanes per record, so one
+// wave-instruction carries 4 whole records as 8-byte lanes of two contiguous 64-byte segments each.
+constexpr int kLogRegions = 64;
+constexpr int kQueueStride = 13;  // u64 words per queued pair (12 deltas + record id); odd stride spreads LDS banks
+
 template <bool PACKED16>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
-                                                   const uint64_t frame_stride, const uint32_t n_pts, const FrameLayout lay,
-                                                   const double* __restrict__ poses, const uint32_t* __restrict__ frame_ids)
+                                                   const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
+                                                   const FrameLayout lay, const double* __restrict__ poses,
+                                                   const uint32_t* __restrict__ frame_ids)
 {
-    const uint32_t f = blockIdx.y;
-    double T[12];
+    __shared__ unsigned long long queue[4][64 * kQueueStride];
+    __shared__ unsigned int blk_ctr[6];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    unsigned long long* q = queue[wave];
+    if (threadIdx.x < 6) blk_ctr[threadIdx.x] = 0;
+
+    const uint32_t tiles_per_frame = (n_pts + 255u) >> 8;
+    const uint64_t n_tiles = (uint64_t)tiles_per_frame * n_frames;
+    const uint32_t region = blockIdx.x & (kLogRegions - 1);
+    unsigned long long* log_ctr = &t.log_ctr[region * 16];
+    const uint64_t log_base = (uint64_t)region * t.log_region_cap;
+    uint32_t c_present = 0, c_z = 0, c_in = 0, c_buf = 0, c_tested = 0, c_member = 0;
+
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t f = (uint32_t)(tile / tiles_per_frame);
+        const uint32_t i = (uint32_t)(tile % tiles_per_frame) * 256u + threadIdx.x;
+        double T[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) T[i] = poses[12 * f + i];
-    const uint32_t fid = frame_ids[f];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (fid < t.max_frames) {  // viewpoint = float(translation), node.cpp:290
+        for (int k = 0; k < 12; k++) T[k] = poses[12 * f + k];
+        const uint32_t fid = frame_ids[f];
+        if (i == 0) {  // viewpoint = float(translation), node.cpp:290
             t.frame_vp[3 * (uint64_t)fid + 0] = (float)T[3];
             t.frame_vp[3 * (uint64_t)fid + 1] = (float)T[7];
             t.frame_vp[3 * (uint64_t)fid + 2] = (float)T[11];
-        } else {
-            atomicOr(&t.ctr[C_ERR], (unsigned long long)E_FRAME);
         }
-    }
-    const uint8_t* __restrict__ base = frames + (uint64_t)f * frame_stride;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t c_present = 0, c_z = 0, c_in = 0, c_buf = 0, c_tested = 0, c_member = 0;
-
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_pts; i0 += stride) {
-        const uint32_t i = i0 + lane;
+        const uint8_t* __restrict__ base = frames + (uint64_t)f * frame_stride;
         bool act = i < n_pts;
         float x = 0.f, y = 0.f, z = 0.f;
         uint32_t rgb = 0;
@@ -66,11 +87,11 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         c_present += act;
         act = act && zclip_pass(g, z);
         c_z += act;
-        const F3 q = transform_point(T, x, y, z);
+        const F3 p = transform_point(T, x, y, z);
         int32_t ix, iy, iz;
-        voxel_coords(g, q, ix, iy, iz);
+        voxel_coords(g, p, ix, iy, iz);
         // A NaN coordinate passes validPoints in the reference and then indexes out of bounds (crash); dropped here.
-        act = act && valid_point(g, q) && ix != INT_MIN && iy != INT_MIN && iz != INT_MIN;
+        act = act && valid_point(g, p) && ix != INT_MIN && iy != INT_MIN && iz != INT_MIN;
         c_in += act;
 
         const uint32_t bidx = act ? brick_index(g, ix, iy, iz) : 0u;
@@ -92,16 +113,17 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             if (oi < t.max_occ) t.occ_list[oi] = slot;
             else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
         }
-        // viewpoint latch = smallest frame id that touched the cell (grid.hpp:229,238)
-        if (act && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
 
-        // buffer while the voxel has no normal (grid.hpp:210-211,230,239)
+        // buffer while the voxel has no normal (grid.hpp:210-211,230,239); the viewpoint latch (smallest frame
+        // id that touched the cell, grid.hpp:229,238) is only ever read before the normal exists.
         const bool buf = act && !(info & kNormal);
-        const unsigned long long li = wave_reserve(&t.ctr[C_LOG], buf);
+        if (buf && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
+        const unsigned long long li = wave_reserve(log_ctr, buf);
         if (buf) {
-            if (li < t.max_log) {
-                t.log_pt[li + 1] = make_float4(q.x, q.y, q.z, __uint_as_float(rgb));
-                t.log_link[li + 1] = slot;
+            if (li < t.log_region_cap) {
+                const uint64_t e = log_base + li + 1;
+                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(rgb));
+                t.log_link[e] = slot;
             } else {
                 atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
             }
@@ -109,38 +131,86 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         c_buf += buf;
 
         // dependant updates (grid.hpp:244-277)
-        if (act) {
-            const uint32_t cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-            const uint64_t off = info >> kDepOffShift;
-            for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t cnt = act ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u;
+        const uint64_t off = info >> kDepOffShift;
+        uint32_t max_cnt = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, o));
+        for (uint32_t j = 0; j < max_cnt; j++) {
+            bool member = false;
+            StatDelta d;
+            uint32_t sid = 0;
+            if (j < cnt) {
                 const DepEntry e = t.dep[off + j];
                 F3 proj;
                 double dist;
                 c_tested++;
-                if (cylinder_member(g, q, F3{e.cx, e.cy, e.cz}, F3{e.nx, e.ny, e.nz}, proj, dist)) {
+                if (cylinder_member(g, p, F3{e.cx, e.cy, e.cz}, F3{e.nx, e.ny, e.nz}, proj, dist)) {
+                    member = true;
                     c_member++;
-                    StatDelta d;
+                    sid = e.sid;
                     stat_delta_zero(d);
                     stat_delta_add(d, g, proj, F3{e.cx, e.cy, e.cz}, dist, rgb);
-                    stat_flush(&t.stats[(uint64_t)e.sid * kStatWords], d);
                 }
             }
+            const unsigned long long mm = __ballot(member);
+            if (mm == 0) continue;
+            const uint32_t n_mem = (uint32_t)__popcll(mm);
+            if (member) {
+                const uint32_t row = (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                unsigned long long* r = q + row * kQueueStride;
+#pragma unroll
+                for (int w = 0; w < SW_USED; w++) r[w] = (unsigned long long)d.v[w];
+                r[SW_USED] = sid;
+            }
+            // same-wave LDS hand-off: the compiler orders ds_write -> ds_read with s_waitcnt lgkmcnt
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t w = lane & 15u;
+            for (uint32_t r0 = 0; r0 < n_mem; r0 += 4) {
+                const uint32_t row = r0 + (lane >> 4);
+                if (row < n_mem && w < SW_USED) {
+                    const unsigned long long* r = q + row * kQueueStride;
+                    const unsigned long long v = r[w];
+                    const uint64_t rec = (uint64_t)r[SW_USED] * kStatWords;
+                    atomicAdd(&t.stats[rec + w], v);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    wave_count(&t.ctr[C_PRESENTED], c_present);
-    wave_count(&t.ctr[C_ZPASS], c_z);
-    wave_count(&t.ctr[C_INBOX], c_in);
-    wave_count(&t.ctr[C_BUFFERED], c_buf);
-    wave_count(&t.ctr[C_DEP_TESTED], c_tested);
-    wave_count(&t.ctr[C_DEP_MEMBER], c_member);
+    // block-level reduction of the diagnostics: one device atomic per counter per block
+    uint32_t cv[6] = {c_present, c_z, c_in, c_buf, c_tested, c_member};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        uint32_t v = cv[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        cv[k] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (cv[k]) atomicAdd(&blk_ctr[k], cv[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && blk_ctr[threadIdx.x]) atomicAdd(&t.ctr[C_PRESENTED + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Link the log entries appended since the last clean into their cells' chains.
-__global__ __launch_bounds__(256) void k_link_log(const Tables t, const uint32_t first, const uint32_t last)
+// Link the log entries appended since the last clean into their cells' chains.  grid.y = log region;
+// [first[r], last[r]] are 1-based global entry indices (empty when first > last).
+struct LinkRanges {
+    uint32_t first[kLogRegions];
+    uint32_t last[kLogRegions];
+};
+__global__ __launch_bounds__(256) void k_link_log(const Tables t, const LinkRanges lr)
 {
-    const uint64_t e = (uint64_t)first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e > last) return;
+    const uint32_t r = blockIdx.y;
+    const uint64_t e = (uint64_t)lr.first[r] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > lr.last[r]) return;
     const uint32_t slot = t.log_link[e];
     t.log_link[e] = atomicExch(&t.buf_head[slot], (uint32_t)e);
 }

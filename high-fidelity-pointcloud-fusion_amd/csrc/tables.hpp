@@ -112,6 +112,8 @@ struct Tables {
     uint64_t* cand_key;    // clean scratch (unsorted / sorted ping-pong handled by the host)
     float* frame_vp;       // 3 per frame id
     unsigned long long* ctr;
+    unsigned long long* log_ctr;  // kLogRegions append counters, one per 128-byte line (index r*16)
+    uint64_t log_region_cap;      // entries per log region
     uint64_t max_bricks, max_log, max_occ, max_normals, max_reg, max_dep, max_frames;
 };
 
@@ -189,7 +191,7 @@ __device__ inline uint32_t brick_acquire_single(const Tables& t, uint32_t bidx)
 __device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bool want)
 {
     uint32_t v = 0;
-    if (want) v = __hip_atomic_load(&t.dir[bidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (want) v = t.dir[bidx];  // plain (cacheable) load; a stale 0 only sends the lane through the atomic path
     bool need = want && (v == 0 || v == kLock);
     unsigned long long m = __ballot(need);
     const uint32_t lane = lane_id();
