@@ -104,12 +104,18 @@ def main():
     dev = grid.device_alloc(n_gen * frame_bytes)
     buf = np.empty(frame_bytes, dtype=np.uint8)
     host_frames = []
+    t_synth = t_up = 0.0
     for f in range(n_gen):
+        ta = time.perf_counter()
         S.frame(seed, f, W, H, poses[f].reshape(3, 4), out=buf)
+        tb = time.perf_counter()
         grid.device_upload(dev + f * frame_bytes, buf)
+        t_synth += tb - ta
+        t_up += time.perf_counter() - tb
         if f < args.host_path_frames:
             host_frames.append(buf.copy())
-    log("rank %d: staged %d frames (%.2f GB) in %.1f s" % (rank, n_gen, n_gen * frame_bytes / 1e9, time.perf_counter() - t_gen))
+    log("rank %d: staged %d frames (%.2f GB) in %.1f s (synth %.1f s, upload %.1f s, %d cpus)" % (
+        rank, n_gen, n_gen * frame_bytes / 1e9, time.perf_counter() - t_gen, t_synth, t_up, os.cpu_count()))
 
     def run_stream(n_frames, timed):
         done = 0

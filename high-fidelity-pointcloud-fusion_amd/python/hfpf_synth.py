@@ -26,6 +26,12 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        # GPU boxes expose every host CPU but grant a small share; an OpenMP team per visible CPU thrashes.
+        try:
+            n = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, n))))
         L = C.CDLL(_LIB_PATH)
         L.hfpf_synth_pose.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_void_p]
         L.hfpf_synth_frame.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p,

@@ -686,8 +686,9 @@ void horacle_probe_center(void* h, const int32_t* idx, uint64_t n, float* out)
     }
 }
 // a11: normal from an occupancy stencil around cell (x,y,z); occ[d] in setK order (size (2k+1)^3).
-// Returns total occupied (valid) count; normal written only if total >= 3.
-int32_t horacle_probe_normal(void* h, int32_t x, int32_t y, int32_t z, const uint8_t* occ, float* normal_out)
+// vp != NULL applies the orientation of grid.hpp:393-396.  Returns total occupied (valid) count;
+// normal written only if total >= 3.
+int32_t horacle_probe_normal(void* h, int32_t x, int32_t y, int32_t z, const uint8_t* occ, const float* vp, float* normal_out)
 {
     Oracle* o = (Oracle*)h;
     std::vector<V3> cloud;
@@ -697,6 +698,10 @@ int32_t horacle_probe_normal(void* h, int32_t x, int32_t y, int32_t z, const uin
     }
     V3 nrm{0, 0, 0};
     if (get_normal(cloud.data(), (int)cloud.size(), nrm)) {
+        if (vp) {
+            V3 dir = normalized3(sub3(V3{vp[0], vp[1], vp[2]}, o->voxel_center(x, y, z)));
+            if (dot3(dir, nrm) < 0.0f) nrm = {nrm.x * -1.0f, nrm.y * -1.0f, nrm.z * -1.0f};
+        }
         normal_out[0] = nrm.x;
         normal_out[1] = nrm.y;
         normal_out[2] = nrm.z;

@@ -76,7 +76,7 @@ def lib():
         L.horacle_probe_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.horacle_probe_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.horacle_probe_center.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-        L.horacle_probe_normal.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.horacle_probe_normal.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.horacle_probe_normal.restype = C.c_int32
         L.horacle_probe_project.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                             C.c_void_p]
@@ -195,10 +195,11 @@ class OracleGrid:
         lib().horacle_probe_center(self._h, _p(idx), idx.shape[0], _p(out))
         return out
 
-    def probe_normal(self, x, y, z, occ):
+    def probe_normal(self, x, y, z, occ, vp=None):
         occ = np.ascontiguousarray(occ, dtype=np.uint8)
         out = np.zeros(3, dtype=np.float32)
-        total = lib().horacle_probe_normal(self._h, x, y, z, _p(occ), _p(out))
+        vpa = None if vp is None else np.ascontiguousarray(vp, dtype=np.float32)
+        total = lib().horacle_probe_normal(self._h, x, y, z, _p(occ), None if vpa is None else _p(vpa), _p(out))
         return total, out
 
 
