@@ -78,6 +78,7 @@ struct hfpf_handle {
     unsigned long long* h_log_ctr = nullptr;  // pinned mirror of the region counters
     int integrate_grid = 1536;
     uint64_t frames_integrated = 0;
+    uint64_t reg_done = 0;  // reg_occ entries already present in dep[]
     uint64_t clean_passes = 0;
     uint32_t next_frame_id = 0;
 
@@ -231,10 +232,12 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.dep_tmp, 0, h->n_slots * 4, s));
     HIPCHK(h, hipMemsetAsync(t.occ_mask, 0, (t.max_bricks + 1) * 8 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.stats, 0, (t.max_normals + 1) * kStatWords * 8, s));
+    if (t.cstats) HIPCHK(h, hipMemsetAsync(t.cstats, 0, (t.max_normals + 1) * 4 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.ctr, 0, C_COUNT * 8, s));
     HIPCHK(h, hipMemsetAsync(t.log_ctr, 0, kLogRegions * 16 * 8, s));
     h->dirty = false;
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
+    h->reg_done = 0;
     h->next_frame_id = 0;
     return HFPF_OK;
 }
@@ -257,7 +260,7 @@ int alloc_tables(hfpf_handle* h)
     t.max_normals = c.max_normals;
     t.max_occ = c.max_normals * 4;
     t.max_reg = c.max_normals * (2ull * (uint64_t)c.K + 1ull);
-    t.max_dep = t.max_reg;
+    t.max_dep = 2 * t.max_reg;  // room for the lists the incremental update relocates
     t.max_frames = c.max_frames;
     h->n_slots = (t.max_bricks + 1) * (uint64_t)kBrickCells;
     h->max_touched = t.max_reg;
@@ -281,9 +284,11 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(nv_c, 3 * (t.max_normals + 1), 0, false);
     ALLOC(nv_n, 3 * (t.max_normals + 1), 0, false);
     ALLOC(stats, (t.max_normals + 1) * kStatWords, 0, false);
+    if (c.flags & HFPF_FLAG_FUSE_COLOR) { ALLOC(cstats, (t.max_normals + 1) * 4, 0, false); }
     ALLOC(reg_occ, t.max_reg, 0, false);
     ALLOC(dep, t.max_dep, 0, false);
     ALLOC(prereg_list, t.max_reg, 0, false);
+    ALLOC(prechg_list, t.max_reg, 0, false);
     ALLOC(touched_list, h->max_touched, 0, false);
     ALLOC(cand_key, t.max_occ, 0, false);
     ALLOC(frame_vp, 3 * t.max_frames);
@@ -452,6 +457,7 @@ int clean_locked(hfpf_handle* h)
     if (n_occ == 0) return HFPF_OK;
 
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_PRECHG, 0ull);
     hipLaunchKernelGGL(k_gate, dim3(blocks_for(n_occ, 256)), dim3(256), 0, s, h->g, t, n_occ);
     HIPCHK(h, hipGetLastError());
     if ((rc = read_counters(h))) return rc;
@@ -468,27 +474,56 @@ int clean_locked(hfpf_handle* h)
     const uint64_t n_steps = n_cand * (2ull * (uint64_t)h->g.K + 1ull);
     hipLaunchKernelGGL(k_register, dim3(blocks_for(n_steps, 256)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand));
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_DEP, 0ull);
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_TOUCHED, 0ull);
     HIPCHK(h, hipGetLastError());
     if ((rc = read_counters(h))) return rc;
     if ((rc = check_device_errors(h))) return rc;
     const uint64_t n_reg = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
     const uint64_t n_pre = std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
-    const uint64_t n_all = n_reg + n_pre;
-    if (n_all > t.max_dep) return fail(h, HFPF_ERR_CAPACITY, "dependant table: %llu entries > %llu", (unsigned long long)n_all, (unsigned long long)t.max_dep);
-    if (n_all) {
-        hipLaunchKernelGGL(k_dep_count, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
+    const uint64_t n_chg = std::min<uint64_t>(h->h_ctr[C_PRECHG], t.max_reg);
+    const uint64_t n_new = n_reg - h->reg_done;
+    // incremental update; a conservative space estimate decides whether to compact instead
+    bool full = h->h_ctr[C_DEP] + 8 * n_new + n_chg > t.max_dep;
+    if (!full) {
+        if (n_new) {
+            hipLaunchKernelGGL(k_depinc_count, dim3(blocks_for(n_new, 256)), dim3(256), 0, s, t, h->reg_done, n_reg);
+            HIPCHK(h, hipGetLastError());
+            if ((rc = read_counters(h))) return rc;
+            const uint64_t n_touched = h->h_ctr[C_TOUCHED];
+            hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+            hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(n_new, 256)), dim3(256), 0, s, t, h->reg_done, n_reg);
+            hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+        }
+        if (n_chg) hipLaunchKernelGGL(k_depinc_pre, dim3(blocks_for(n_chg, 256)), dim3(256), 0, s, t, n_chg);
         HIPCHK(h, hipGetLastError());
         if ((rc = read_counters(h))) return rc;
-        const uint64_t n_touched = h->h_ctr[C_TOUCHED];
-        hipLaunchKernelGGL(k_dep_offsets, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
-        hipLaunchKernelGGL(k_dep_fill, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
-        hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
-        HIPCHK(h, hipGetLastError());
+        if (h->h_ctr[C_ERR] == (unsigned long long)E_DEP) {  // dep[] ran out mid-way: compact
+            hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_ERR, 0ull);
+            full = true;
+        } else if ((rc = check_device_errors(h))) {
+            return rc;
+        }
     }
-    if ((rc = read_counters(h))) return rc;
-    return check_device_errors(h);
+    if (full) {
+        const uint64_t n_all = n_reg + n_pre;
+        if (n_all > t.max_dep) return fail(h, HFPF_ERR_CAPACITY, "dependant table: %llu entries > %llu", (unsigned long long)n_all, (unsigned long long)t.max_dep);
+        hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_DEP, 0ull);
+        hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_TOUCHED, 0ull);
+        if (n_all) {
+            hipLaunchKernelGGL(k_dep_count, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
+            HIPCHK(h, hipGetLastError());
+            if ((rc = read_counters(h))) return rc;
+            const uint64_t n_touched = h->h_ctr[C_TOUCHED];
+            hipLaunchKernelGGL(k_dep_offsets, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+            hipLaunchKernelGGL(k_dep_fill, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
+            hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+            HIPCHK(h, hipGetLastError());
+        }
+        if ((rc = read_counters(h))) return rc;
+        if ((rc = check_device_errors(h))) return rc;
+    }
+    h->reg_done = n_reg;
+    return HFPF_OK;
 }
 
 }  // namespace
@@ -779,7 +814,7 @@ int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)
     out->voxels_with_normal = c[C_NORMALS];
     out->bricks_allocated = std::min<uint64_t>(c[C_BRICKS], h->t.max_bricks);
     out->registrations = c[C_REG];
-    out->dep_entries = c[C_DEP];
+    out->dep_entries = c[C_DEP];  /* includes relocated (garbage) lists until the next compaction */
     out->frames_integrated = h->frames_integrated;
     out->clean_passes = h->clean_passes;
     out->device_bytes = h->device_bytes;

@@ -25,13 +25,14 @@ struct FrameLayout {
 // issuer (MI355X_MICROARCH.md "fanin"), so diagnostics stay in registers until the block retires and the
 // point log is striped over kLogRegions append regions with one counter per 128-byte line.
 //
-// Dependant updates: every (point, dependant) pair that falls inside the 1 mm cylinder adds 12 int64
-// words to ONE 128-byte statistics record.  A lane-per-pair loop would issue 12 fully scattered atomic
-// instructions per round (64 lanes x 12 = 768 memory-side requests); instead the member lanes park their
-// deltas in a per-wave LDS queue and the wave replays the queue with 16 lanes per record, so one
-// wave-instruction carries 4 whole records as 8-byte lanes of two contiguous 64-byte segments each.
+// Dependant updates: every (point, dependant) pair that falls inside the 1 mm cylinder adds 7 int64
+// words to ONE 64-byte statistics record.  A lane-per-pair loop would issue 7 fully scattered atomic
+// instructions per round (64 lanes x 7 = 448 memory-side requests); instead the member lanes park their
+// deltas in a per-wave LDS queue and the wave replays the queue with 8 lanes per record, so one
+// wave-instruction carries 8 whole records, each as 8-byte lanes of one contiguous 64-byte segment
+// (64 requests per round at most, measured 1.8x faster than two segments per record).
 constexpr int kLogRegions = 64;
-constexpr int kQueueStride = 13;  // u64 words per queued pair (12 deltas + record id); odd stride spreads LDS banks
+constexpr int kQueueStride = 9;  // u64 words per queued pair (7 deltas + record id + rgb); odd stride spreads LDS banks
 
 template <bool PACKED16>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
@@ -161,19 +162,30 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
                 unsigned long long* r = q + row * kQueueStride;
 #pragma unroll
                 for (int w = 0; w < SW_USED; w++) r[w] = (unsigned long long)d.v[w];
-                r[SW_USED] = sid;
+                r[7] = sid;
+                r[8] = rgb;
             }
-            // same-wave LDS hand-off: the compiler orders ds_write -> ds_read with s_waitcnt lgkmcnt
+            // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t w = lane & 15u;
-            for (uint32_t r0 = 0; r0 < n_mem; r0 += 4) {
-                const uint32_t row = r0 + (lane >> 4);
-                if (row < n_mem && w < SW_USED) {
-                    const unsigned long long* r = q + row * kQueueStride;
-                    const unsigned long long v = r[w];
-                    const uint64_t rec = (uint64_t)r[SW_USED] * kStatWords;
-                    atomicAdd(&t.stats[rec + w], v);
+            {
+                const uint32_t w = lane & 7u;
+                for (uint32_t r0 = 0; r0 < n_mem; r0 += 8) {
+                    const uint32_t row = r0 + (lane >> 3);
+                    if (row < n_mem && w < SW_USED) {
+                        const unsigned long long* r = q + row * kQueueStride;
+                        atomicAdd(&t.stats[(uint64_t)r[7] * kStatWords + w], r[w]);
+                    }
+                }
+            }
+            if (t.cstats) {  // optional colour fusion: 4 lanes per record, 16 records per wave-instruction
+                const uint32_t w = lane & 3u;
+                for (uint32_t r0 = 0; r0 < n_mem; r0 += 16) {
+                    const uint32_t row = r0 + (lane >> 2);
+                    if (row < n_mem && w < 3) {
+                        const unsigned long long* r = q + row * kQueueStride;
+                        atomicAdd(&t.cstats[(uint64_t)r[7] * 4 + w], (r[8] >> (16 - 8 * w)) & 255ull);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -344,11 +356,20 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         if (ri < t.max_reg) t.reg_occ[ri] = make_uint2(slot, (uint32_t)nid);  // dependants.push_back, grid.hpp:417
         else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
     }
-    bool newpre = false;
-    if (unocc) newpre = atomicMax(&t.pre_dep[slot], (uint32_t)nid) == 0u;
+    bool newpre = false, chgpre = false;
+    if (unocc) {
+        const uint32_t old = atomicMax(&t.pre_dep[slot], (uint32_t)nid);
+        newpre = old == 0u;        // first registration ever on this cell
+        chgpre = old <= base;      // first change in THIS pass (ids of this pass are > base): exactly one lane sees it
+    }
     const unsigned long long pi = wave_reserve(&t.ctr[C_PREREG], newpre);
     if (newpre) {
         if (pi < t.max_reg) t.prereg_list[pi] = slot;
+        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
+    }
+    const unsigned long long ci = wave_reserve(&t.ctr[C_PRECHG], chgpre);
+    if (chgpre) {
+        if (ci < t.max_reg) t.prechg_list[ci] = slot;
         else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
     }
     if (occ) {  // replay the cell's buffered points through this voxel's cylinder (grid.hpp:418-440)
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
             if (cylinder_member(g, F3{p.x, p.y, p.z}, c, n, proj, dist)) stat_delta_add(d, g, proj, c, dist, __float_as_uint(p.w));
             e = t.log_link[e];
         }
-        if (d.v[SW_COUNT]) stat_flush(&t.stats[nid * kStatWords], d);
+        if (d.v[SW_COUNT]) stat_flush(t, nid, d);
     }
 }
 
@@ -424,6 +445,90 @@ __global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_
     if (j < n_touched) t.dep_tmp[t.touched_list[j]] = 0;
 }
 
+
+// ---- incremental dependant-table update ---------------------------------------------------------------
+// A clean pass only appends registrations (occupied targets) or replaces the single entry of an
+// unoccupied target, so only the cells touched by THIS pass are rewritten: their old list is copied to
+// fresh space at the end of dep[] and the new entries appended.  The space of the old list is garbage
+// until the next full rebuild (k_dep_count / k_dep_offsets / k_dep_fill), which the host runs when dep[]
+// fills up.
+__device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid)
+{
+    DepEntry e;
+    e.sid = nid;
+    e.cx = t.nv_c[3 * (uint64_t)nid];
+    e.cy = t.nv_c[3 * (uint64_t)nid + 1];
+    e.cz = t.nv_c[3 * (uint64_t)nid + 2];
+    e.nx = t.nv_n[3 * (uint64_t)nid];
+    e.ny = t.nv_n[3 * (uint64_t)nid + 1];
+    e.nz = t.nv_n[3 * (uint64_t)nid + 2];
+    e.pad = 0;
+    return e;
+}
+
+__global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg)
+{
+    const uint64_t j = reg_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool fresh = false;
+    uint32_t slot = 0;
+    if (j < n_reg) {
+        slot = t.reg_occ[j].x;
+        fresh = atomicAdd(&t.dep_tmp[slot], 1u) == 0u;
+    }
+    const unsigned long long ti = wave_reserve(&t.ctr[C_TOUCHED], fresh);
+    if (fresh) t.touched_list[ti] = slot;
+}
+
+__global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_touched) return;
+    const uint32_t slot = t.touched_list[j];
+    const uint64_t info = t.info[slot];
+    const uint32_t old_cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+    const uint64_t old_off = info >> kDepOffShift;
+    const uint32_t add = t.dep_tmp[slot];
+    uint32_t new_cnt = old_cnt + add;
+    const unsigned long long new_off = atomicAdd(&t.ctr[C_DEP], (unsigned long long)new_cnt);
+    if (new_off + new_cnt > t.max_dep || new_cnt > kDepCntMask) {  // host falls back to a full (compacting) rebuild
+        atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
+        t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
+        return;
+    }
+    for (uint32_t k = 0; k < old_cnt; k++) t.dep[new_off + k] = t.dep[old_off + k];
+    t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)new_off << kDepOffShift);
+    t.dep_tmp[slot] = old_cnt;  // append cursor
+}
+
+__global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint64_t reg_first, const uint64_t n_reg)
+{
+    const uint64_t j = reg_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_reg) return;
+    const uint2 r = t.reg_occ[j];
+    const uint32_t k = atomicAdd(&t.dep_tmp[r.x], 1u);
+    if (k & 0x80000000u) return;
+    t.dep[(t.info[r.x] >> kDepOffShift) + k] = make_dep_entry(t, r.y);
+}
+
+// Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).
+__global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64_t n_chg)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_chg) return;
+    const uint32_t slot = t.prechg_list[j];
+    const uint64_t info = t.info[slot];
+    uint64_t off = info >> kDepOffShift;
+    if (((info >> kDepCntShift) & kDepCntMask) == 0) {
+        off = atomicAdd(&t.ctr[C_DEP], 1ull);
+        if (off >= t.max_dep) {
+            atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEP);
+            return;
+        }
+        t.info[slot] = (info & 3ull) | (1ull << kDepCntShift) | (off << kDepOffShift);
+    }
+    t.dep[off] = make_dep_entry(t, t.pre_dep[slot]);
+}
+
 // ---- K6 extract -----------------------------------------------------------------------------------
 // Keys of the records that downloadData would emit: x<xdim && y<ydim && z<zdim (grid.hpp:463-465);
 // others get the all-ones key and sort to the end.
@@ -483,21 +588,25 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
         r.x = (float)((double)t.nv_c[3 * nid] + mx);
         r.y = (float)((double)t.nv_c[3 * nid + 1] + my);
         r.z = (float)((double)t.nv_c[3 * nid + 2] + mz);
-        double vx = ((double)s[SW_S2 + 0] / g.s2_scale) * inv - mx * mx;
-        double vy = ((double)s[SW_S2 + 1] / g.s2_scale) * inv - my * my;
-        double vz = ((double)s[SW_S2 + 2] / g.s2_scale) * inv - mz * mz;
+        // projections lie on the voxel's line: per-axis variance = n_i^2 * var(t), var(t) = E|o|^2 - |E o|^2 (stats.hpp)
+        double vt = ((double)s[SW_S2] / g.s2_scale) * inv - ((mx * mx + my * my) + mz * mz);
         const double md = ((double)s[SW_D] / g.sd_scale) * inv;
         double vd = ((double)s[SW_DD] / g.sdd_scale) * inv - md * md;
-        if (cnt == 1) vx = vy = vz = vd = 0.0;  // the recurrence gives exactly 0 for a single sample
-        r.sdx = (float)fmax(vx, 0.0);
-        r.sdy = (float)fmax(vy, 0.0);
-        r.sdz = (float)fmax(vz, 0.0);
+        if (cnt == 1) vt = vd = 0.0;  // the recurrence gives exactly 0 for a single sample
+        vt = fmax(vt, 0.0);
+        r.sdx = (float)((double)r.nx * (double)r.nx * vt);
+        r.sdy = (float)((double)r.ny * (double)r.ny * vt);
+        r.sdz = (float)((double)r.nz * (double)r.nz * vt);
         r.mean_dist = (float)md;
         r.sd_dist = (float)fmax(vd, 0.0);
-        const uint32_t cr = (uint32_t)(((double)s[SW_RGB + 0] * inv) + 0.5);
-        const uint32_t cg = (uint32_t)(((double)s[SW_RGB + 1] * inv) + 0.5);
-        const uint32_t cb = (uint32_t)(((double)s[SW_RGB + 2] * inv) + 0.5);
-        r.rgb = (min(cr, 255u) << 16) | (min(cg, 255u) << 8) | min(cb, 255u);
+        r.rgb = 0;
+        if (t.cstats) {
+            const long long* cs = reinterpret_cast<const long long*>(&t.cstats[nid * 4]);
+            const uint32_t cr = (uint32_t)(((double)cs[0] * inv) + 0.5);
+            const uint32_t cg = (uint32_t)(((double)cs[1] * inv) + 0.5);
+            const uint32_t cb = (uint32_t)(((double)cs[2] * inv) + 0.5);
+            r.rgb = (min(cr, 255u) << 16) | (min(cg, 255u) << 8) | min(cb, 255u);
+        }
     }
     rows[j] = r;
 }

@@ -3,36 +3,44 @@
 // The reference keeps float Welford recurrences per voxel (grid.hpp:264-273, 428-438): count, centroid,
 // per-axis sd, mean_dist, sd_dist.  Those depend on the order in which points arrive.  The engine
 // instead accumulates exact integer sums, so any interleaving of threads, frames or GPUs gives the
-// same bits, and merging two GPUs' partial records is a plain integer add:
+// same bits, and merging two GPUs' partial records is a plain integer add.
+//
+// One record = 8 int64 words = 64 bytes = ONE memory-side atomic segment (the chip retires ~20 G such
+// segments per second however few bytes each carries, so the record is sized to be exactly one):
 //
 //   word 0      count
-//   words 1-3   sum of (proj_i - c_i) * 2^e1          c = cell centre of the record's voxel (f32)
-//   words 4-6   sum of (proj_i - c_i)^2 * 2^e2
-//   word 7      sum of dist * 2^ed                    dist = (double)||p - proj||_f32  (grid.hpp:261)
-//   word 8      sum of dist^2 * 2^edd
-//   words 9-11  sum of r, g, b of the member points   (extension: the reference never fuses colour)
-//   words 12-15 unused (record = 128 bytes = two 64-byte atomic segments)
+//   words 1-3   sum of o_i * 2^e1,  o = proj - c,  c = cell centre of the record's voxel (f32, exact in f64)
+//   word 4      sum of |o|^2 * 2^e2
+//   word 5      sum of dist * 2^ed                    dist = (double)||p - proj||_f32  (grid.hpp:261)
+//   word 6      sum of dist^2 * 2^edd
+//   word 7      unused
 //
-// proj_i - c_i is exact in f64 (both are f32 within a few voxels of each other); each sample is
-// rounded once to the fixed-point grid (<= 2^-e1 / 2 absolute).  The exponents are chosen at create
-// time so that 2^25 samples per voxel cannot overflow an int64.  hfpf_extract turns the sums into
-// the reference's quantities: mean = c + S1/n, sd = S2/n - (S1/n)^2 (the Welford recurrence of
-// grid.hpp:267 is the population variance), mean_dist = Sd/n, sd_dist = Sdd/n - mean_dist^2.
+// Every projected point lies on the voxel's line (proj = a - s*ab with ab || n, grid.hpp:40-49), i.e.
+// o = t*n up to f32 rounding of the projection itself (~6e-8 m), so the reference's per-axis variance is
+// sd_i = n_i^2 * var(t) with var(t) = E|o|^2 - |E o|^2; one second-moment word replaces three.  The
+// deviation from three exact per-axis sums is below the rounding noise of the reference's own f32
+// recurrence.
+//
+// Optional colour record (HFPF_FLAG_FUSE_COLOR; the reference never fuses colour): 4 words, sum r,g,b.
+//
+// Exponents are chosen at create time so that 2^25 samples per voxel cannot overflow an int64.
 #pragma once
 #include "tables.hpp"
 
 namespace hfpf {
 
-enum StatWord : int { SW_COUNT = 0, SW_S1 = 1, SW_S2 = 4, SW_D = 7, SW_DD = 8, SW_RGB = 9, SW_USED = 12 };
+enum StatWord : int { SW_COUNT = 0, SW_S1 = 1, SW_S2 = 4, SW_D = 5, SW_DD = 6, SW_USED = 7 };
 
 struct StatDelta {
     long long v[SW_USED];
+    long long rgb[3];
 };
 
 __device__ __forceinline__ void stat_delta_zero(StatDelta& d)
 {
 #pragma unroll
     for (int i = 0; i < SW_USED; i++) d.v[i] = 0;
+    d.rgb[0] = d.rgb[1] = d.rgb[2] = 0;
 }
 
 // Contribution of one cylinder member.
@@ -45,21 +53,25 @@ __device__ __forceinline__ void stat_delta_add(StatDelta& d, const GridParams& g
     d.v[SW_S1 + 0] += __double2ll_rn(ox * g.s1_scale);
     d.v[SW_S1 + 1] += __double2ll_rn(oy * g.s1_scale);
     d.v[SW_S1 + 2] += __double2ll_rn(oz * g.s1_scale);
-    d.v[SW_S2 + 0] += __double2ll_rn((ox * ox) * g.s2_scale);
-    d.v[SW_S2 + 1] += __double2ll_rn((oy * oy) * g.s2_scale);
-    d.v[SW_S2 + 2] += __double2ll_rn((oz * oz) * g.s2_scale);
+    d.v[SW_S2] += __double2ll_rn(((ox * ox + oy * oy) + oz * oz) * g.s2_scale);
     d.v[SW_D] += __double2ll_rn(dist * g.sd_scale);
     d.v[SW_DD] += __double2ll_rn((dist * dist) * g.sdd_scale);
-    d.v[SW_RGB + 0] += (long long)((rgb >> 16) & 255u);
-    d.v[SW_RGB + 1] += (long long)((rgb >> 8) & 255u);
-    d.v[SW_RGB + 2] += (long long)(rgb & 255u);
+    d.rgb[0] += (long long)((rgb >> 16) & 255u);
+    d.rgb[1] += (long long)((rgb >> 8) & 255u);
+    d.rgb[2] += (long long)(rgb & 255u);
 }
 
-__device__ __forceinline__ void stat_flush(unsigned long long* rec, const StatDelta& d)
+__device__ __forceinline__ void stat_flush(const Tables& t, uint64_t sid, const StatDelta& d)
 {
+    unsigned long long* rec = &t.stats[sid * kStatWords];
 #pragma unroll
     for (int i = 0; i < SW_USED; i++)
         if (d.v[i] != 0) atomicAdd(rec + i, (unsigned long long)d.v[i]);
+    if (t.cstats) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (d.rgb[i] != 0) atomicAdd(&t.cstats[sid * 4 + i], (unsigned long long)d.rgb[i]);
+    }
 }
 
 }  // namespace hfpf

@@ -19,7 +19,7 @@
 //                                    of grid.hpp:334-349 becomes <= 20 u64 loads.
 //   point log: log_pt float4 (x,y,z,rgb bits) + log_link u32 (slot until linked, then `next`): the
 //              reference's per-voxel buffers (grid.hpp:70,211,230) as one append-only array.
-//   normals:   nv_key u64, nv_slot u32, nv_c/nv_n float3, stats[16] i64 per record (stats.hpp)
+//   normals:   nv_key u64, nv_slot u32, nv_c/nv_n float3, stats[8] i64 per record (stats.hpp)
 //   dependants: reg_occ (slot, stat id) pairs, append-only; dep[] = 32-byte entries grouped per slot,
 //              rebuilt by every clean pass (VoxelInfo::dependants, grid.hpp:71,417,447).
 #pragma once
@@ -62,6 +62,7 @@ enum Ctr : int {
     C_DEP_TESTED,
     C_DEP_MEMBER,
     C_ROWS,         // rows valid at extract
+    C_PRECHG,       // unoccupied cells whose single dependant changed in the running clean pass
     C_COUNT = 32
 };
 
@@ -85,7 +86,7 @@ struct __attribute__((aligned(32))) DepEntry {  // one dependant of a cell, deno
 };
 static_assert(sizeof(DepEntry) == 32, "DepEntry must be 32 bytes");
 
-constexpr int kStatWords = 16;  // i64 words per statistics record (128 B): see stats.hpp
+constexpr int kStatWords = 8;  // i64 words per statistics record (64 B = one atomic segment): see stats.hpp
 
 struct Tables {
     uint32_t* dir;
@@ -105,9 +106,11 @@ struct Tables {
     float* nv_c;  // 3 per record
     float* nv_n;  // 3 per record
     unsigned long long* stats;
+    unsigned long long* cstats;  // optional colour sums, 4 words per record (NULL unless HFPF_FLAG_FUSE_COLOR)
     uint2* reg_occ;
     DepEntry* dep;
     uint32_t* prereg_list;
+    uint32_t* prechg_list;
     uint32_t* touched_list;
     uint64_t* cand_key;    // clean scratch (unsorted / sorted ping-pong handled by the host)
     float* frame_vp;       // 3 per frame id

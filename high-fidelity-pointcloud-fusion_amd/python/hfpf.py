@@ -20,6 +20,7 @@ PKG_DIR = os.path.dirname(_HERE)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libhfpf.so")
 
+FLAG_FUSE_COLOR = 1
 STATUS = {0: "OK", -1: "BAD_CONFIG", -2: "BAD_ARG", -3: "CAPACITY", -4: "HIP", -5: "STATE", -6: "IO", -7: "DIST"}
 
 
@@ -143,7 +144,7 @@ class OccupancyGrid:
     """Device-resident occupancy grid.  Keyword defaults are the reference's constants."""
 
     def __init__(self, resolution=None, bbox=None, k=None, K=None, gate=None, cylinder_radius=None, ball_radius=None,
-                 z_clip=None, device=0, max_bricks=0, max_log_points=0, max_normals=0, max_frames=0):
+                 z_clip=None, device=0, max_bricks=0, max_log_points=0, max_normals=0, max_frames=0, fuse_color=False):
         L = lib()
         c = default_config()
         if resolution is not None:
@@ -160,6 +161,7 @@ class OccupancyGrid:
         if z_clip is not None:
             c.z_clip_min, c.z_clip_max = z_clip
         c.device = device
+        c.flags = FLAG_FUSE_COLOR if fuse_color else 0
         c.max_bricks, c.max_log_points, c.max_normals, c.max_frames = max_bricks, max_log_points, max_normals, max_frames
         self.cfg = c
         self._h = C.c_void_p()

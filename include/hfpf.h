@@ -24,6 +24,9 @@ extern "C" {
 
 #define HFPF_ABI_VERSION 1
 
+/* hfpf_config.flags */
+#define HFPF_FLAG_FUSE_COLOR 1u /* EXTENSION: also average the member points' RGB per voxel (reference: never, grid.hpp:471-479) */
+
 typedef struct hfpf_handle hfpf_handle;
 
 typedef enum hfpf_status {
@@ -53,7 +56,7 @@ typedef struct hfpf_config {
     double z_clip_min;        /* kZmin, node.cpp:92 = 0.28 (camera frame, strict) */
     double z_clip_max;        /* kZmax, node.cpp:93 = 0.6 */
     int32_t device;           /* HIP device ordinal */
-    uint32_t flags;           /* reserved, 0 */
+    uint32_t flags;           /* HFPF_FLAG_*; 0 = the reference's behaviour */
     /* Device pool capacities; 0 = engine default.  The reference grows without bound (README:12). */
     uint64_t max_bricks;      /* 8x8x8-voxel bricks that may be touched */
     uint64_t max_log_points;  /* points buffered while their voxel has no normal (grid.hpp:211,230) */
@@ -70,7 +73,7 @@ typedef struct hfpf_row {
     float sdx, sdy, sdz; /* VoxelInfo::sd (population variance per axis, as the reference's Welford recurrence) */
     float mean_dist;     /* VoxelInfo::mean_dist */
     float sd_dist;       /* VoxelInfo::sd_dist */
-    uint32_t rgb;        /* EXTENSION: mean colour of the cylinder members, 0x00RRGGBB (the reference never writes rgb) */
+    uint32_t rgb;        /* 0 (the reference never writes rgb); with HFPF_FLAG_FUSE_COLOR: mean colour of the cylinder members, 0x00RRGGBB */
 } hfpf_row;
 
 typedef struct hfpf_counters {

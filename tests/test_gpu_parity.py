@@ -54,3 +54,78 @@ def test_pcl32_layout(oracle_mod, hfpf_mod, synth_mod):
     ref, got, occ_ref, occ_got, oc, ctr = _both(oracle_mod, hfpf_mod, sc)
     assert np.array_equal(occ_ref, occ_got)
     scenes.compare_rows(ref, got)
+
+
+def test_compacting_rebuild_path(oracle_mod, hfpf_mod, synth_mod):
+    """max_normals just above the need: the incremental dependant-table update runs out of room and the engine
+    falls back to the full (compacting) rebuild; rows must not change."""
+    sc = scenes.Scene(6, 160, 120, 0.001, fx=615.0, clean_every=1)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ref = scenes.run(og, sc, "capture")
+    cap = dict(SMALL)
+    cap["max_normals"] = int(len(ref) * 1.3) + 64
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **cap) as eg:
+        got = scenes.run(eg, sc, "integrate")
+    scenes.compare_rows(ref, got)
+
+
+def test_capacity_overflow_is_reported(hfpf_mod, synth_mod):
+    sc = scenes.Scene(2, 160, 120, 0.001, fx=615.0)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, max_bricks=8, max_log_points=1 << 20, max_normals=1 << 16, max_frames=8) as eg:
+        eg.integrate(sc.frame(0), sc.poses[0])
+        with pytest.raises(hfpf_mod.HfpfError) as e:
+            eg.clean()
+        assert e.value.code == -3 and "brick" in str(e.value)
+
+
+def test_colour_extension_does_not_change_geometry(hfpf_mod, synth_mod):
+    """HFPF_FLAG_FUSE_COLOR (extension; the reference never fuses colour): same rows, plus the member points' mean RGB."""
+    sc = scenes.Scene(5, 160, 120, 0.001, fx=615.0, clean_every=2)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as a:
+        ra = scenes.run(a, sc, "integrate")
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, fuse_color=True, **SMALL) as b:
+        rb = scenes.run(b, sc, "integrate")
+    assert (ra["rgb"] == 0).all()
+    for f in ra.dtype.names:
+        if f != "rgb":
+            assert np.array_equal(ra[f], rb[f]), f
+    assert (rb["rgb"][rb["count"] == 0] == 0).all()
+    has = rb["count"] > 3
+    r = (rb["rgb"][has] >> 16) & 255
+    assert 60 < r.mean() < 195  # mean of hash colours sits mid-range
+
+
+def test_clear_then_rerun_is_identical(hfpf_mod, synth_mod):
+    sc = scenes.Scene(4, 160, 120, 0.005, clean_every=2)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as g:
+        r1 = scenes.run(g, sc, "integrate")
+        g.clear()
+        assert g.state_changed
+        assert len(g.extract()) == 0
+        r2 = scenes.run(g, sc, "integrate")
+    assert r1.tobytes() == r2.tobytes()  # integer sums: bitwise reproducible run to run
+
+
+def test_batched_device_frames_equal_single_host_frames(hfpf_mod, synth_mod):
+    """hfpf_integrate_device with several frames per launch == one hfpf_integrate per frame (order-free sums)."""
+    sc = scenes.Scene(6, 160, 120, 0.001, fx=615.0)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as a:
+        for f in range(3):
+            a.integrate(sc.frame(f), sc.poses[f])
+        a.clean()
+        for f in range(3, 6):
+            a.integrate(sc.frame(f), sc.poses[f])
+        a.clean()
+        ra = a.extract()
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as b:
+        fb = sc.W * sc.H * 16
+        dev = b.device_alloc(6 * fb)
+        for f in range(6):
+            b.device_upload(dev + f * fb, sc.frame(f))
+        b.integrate_device(dev, 3, fb, sc.W * sc.H, np.stack(sc.poses[:3]))
+        b.clean()
+        b.integrate_device(dev + 3 * fb, 3, fb, sc.W * sc.H, np.stack(sc.poses[3:]))
+        b.clean()
+        rb = b.extract()
+        b.device_free(dev)
+    assert ra.tobytes() == rb.tobytes()
