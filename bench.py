@@ -92,11 +92,25 @@ def main():
     n_gen = max(K, Wm)
     poses = make_stream(seed, pose_seed, n_gen)
 
-    grid = hfpf.OccupancyGrid(resolution=RES, bbox=BBOX, device=local_rank, max_bricks=400000,
+    device = local_rank
+    if world > 1:
+        import torch
+        n_dev = torch.cuda.device_count()  # does not initialise the GPU
+        if n_dev > 0:
+            device = local_rank % n_dev  # rehearsals with more ranks than GPUs share devices (RCCL then falls back)
+    grid = hfpf.OccupancyGrid(resolution=RES, bbox=BBOX, device=device, max_bricks=400000,
                               max_log_points=min(max(n_gen, 64) * NPTS, 1 << 31), max_normals=24 << 20,
                               max_frames=max(n_gen * max(world, 1) + 16, 4096))
+    transport = "none"
     if world > 1:
-        grid.dist_init(rank, world, dist)
+        import hfpf_dist
+        try:  # data path = the engine's own RCCL collectives over xGMI
+            hfpf_dist.init_rccl(grid, dist, hfpf)
+            transport = "rccl"
+        except hfpf.HfpfError as e:  # keep measuring: stage the same exchange through the launcher's process group
+            log("rank %d: RCCL bootstrap failed (%s); falling back to the host-staged transport" % (rank, e))
+            grid.attach_transport(hfpf_dist.HostStagedTransport(dist))
+            transport = "host-staged (gloo)"
 
     # ---- stage frames in HBM (not timed) ----
     t_gen = time.perf_counter()
@@ -125,7 +139,7 @@ def main():
             if args.clean_every:
                 nxt = min(nxt, (done // args.clean_every + 1) * args.clean_every)
             b = min(B, nxt - done)
-            ids = (np.arange(done, done + b, dtype=np.uint32) * world + rank).astype(np.uint32)
+            ids = ((np.arange(done, done + b, dtype=np.int64) * world) + rank).astype(np.uint32)  # global frame ids
             grid.integrate_device(dev + done * frame_bytes, b, frame_bytes, NPTS, poses[done:done + b], frame_ids=ids)
             done += b
             if args.clean_every and done % args.clean_every == 0 and done < n_frames:
@@ -198,7 +212,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d-frame synthetic 640x480 stream, random SE(3) poses, 1 m^3 bbox @ 1 mm, "
                                    "clean every %d frames + final clean" % (K, args.clean_every),
-                       "points_per_step": NPTS, "frames_per_call": args.frames_per_call, "parallelism": "frames sharded, %d rank(s)" % world},
+                       "points_per_step": NPTS, "frames_per_call": args.frames_per_call, "parallelism": "one camera stream per GPU, %d rank(s), transport %s" % (world, transport)},
             "extract_s": round(extract_s, 5),
             "rows_extracted": int(len(rows)),
             "integrate_kernel_mpts": round(K * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,

@@ -9,6 +9,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -90,6 +92,15 @@ struct hfpf_handle {
     // scratch
     DevBuf sort_tmp, keys_a, keys_b, vals_a, vals_b, rows_dev, probe_a, probe_b, probe_c, probe_d, probe_e, probe_f;
     unsigned long long* h_ctr = nullptr;  // pinned mirror of the counters
+
+    // multi-GPU: RCCL is resolved at run time so a single-GPU user needs no librccl
+    bool dist_on = false;
+    int rank = 0, world = 1;
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;  // ncclComm_t
+    uint64_t occ_exported = 0;  // occ_list entries already exchanged
+    DevBuf ex_send, ex_recv, ex_counts, stats_total, cstats_total;
+    unsigned long long* h_counts = nullptr;  // pinned, world entries
 
     // kernel timing
     bool timing = false;
@@ -238,6 +249,7 @@ int reset_state(hfpf_handle* h)
     h->dirty = false;
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
     h->reg_done = 0;
+    h->occ_exported = 0;
     h->next_frame_id = 0;
     return HFPF_OK;
 }
@@ -426,15 +438,132 @@ int resolve_timing(hfpf_handle* h)
     return HFPF_OK;
 }
 
+
+// ---- RCCL, resolved with dlopen/dlsym ---------------------------------------------------------------
+// (same ABI as <rccl/rccl.h>; declared here so libhfpf.so has no link-time dependency on librccl)
+typedef struct ncclComm* ncclComm_t_;
+typedef struct { char internal[128]; } ncclUniqueId_;
+enum { ncclSuccess_ = 0 };
+enum { ncclChar_ = 0, ncclUint64_ = 5 };  // ncclInt8/ncclChar = 0, ncclUint64 = 5 (rccl.h ncclDataType_t)
+enum { ncclSum_ = 0 };
+struct RcclApi {
+    int (*GetUniqueId)(ncclUniqueId_*) = nullptr;
+    int (*CommInitRank)(ncclComm_t_*, int, ncclUniqueId_, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t_) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    void* lib = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mtx;
+
+int load_rccl(std::string& err)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mtx);
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) {
+        err = std::string("cannot load librccl: ") + dlerror();
+        return -1;
+    }
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.AllReduce) {
+        err = "librccl lacks a required symbol";
+        return -1;
+    }
+    g_rccl = a;
+    return 0;
+}
+
+#define NCCLCHK(h, call)                                                                                              \
+    do {                                                                                                              \
+        int r_ = (call);                                                                                              \
+        if (r_ != ncclSuccess_)                                                                                       \
+            return fail(h, HFPF_ERR_DIST, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+    } while (0)
+
+// Export the cells this handle occupied since the last exchange into h->ex_send; returns the count.
+int epoch_export_locked(hfpf_handle* h, uint64_t* n_out, uint64_t min_capacity_records)
+{
+    int rc = read_counters(h);
+    if (rc) return rc;
+    if ((rc = check_device_errors(h))) return rc;
+    const uint64_t n_occ = std::min<uint64_t>(h->h_ctr[C_OCC], h->t.max_occ);
+    const uint64_t n_new = n_occ - std::min(n_occ, h->occ_exported);
+    if ((rc = scratch(h, h->ex_send, std::max<uint64_t>(std::max(n_new, min_capacity_records), 1) * sizeof(EpochRec)))) return rc;
+    if (n_new) {
+        hipLaunchKernelGGL(k_epoch_export, dim3(blocks_for(n_new, 256)), dim3(256), 0, h->stream, h->g, h->t, h->occ_exported, n_occ, (EpochRec*)h->ex_send.p);
+        HIPCHK(h, hipGetLastError());
+    }
+    *n_out = n_new;
+    return HFPF_OK;
+}
+
+int epoch_import_locked(hfpf_handle* h, const void* dev_records, uint64_t n)
+{
+    if (n == 0) return HFPF_OK;
+    hipLaunchKernelGGL(k_epoch_import, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, h->t, (const EpochRec*)dev_records, n);
+    HIPCHK(h, hipGetLastError());
+    return HFPF_OK;
+}
+
+// RCCL exchange at the head of a clean pass: all-gather the counts, then the (padded) record lists.
+int dist_exchange_locked(hfpf_handle* h)
+{
+    uint64_t n_mine = 0;
+    int rc = epoch_export_locked(h, &n_mine, 0);
+    if (rc) return rc;
+    if ((rc = scratch(h, h->ex_counts, (size_t)(h->world + 1) * 8))) return rc;
+    unsigned long long* d_counts = (unsigned long long*)h->ex_counts.p;
+    h->h_counts[h->world] = n_mine;
+    HIPCHK(h, hipMemcpyAsync(d_counts + h->world, h->h_counts + h->world, 8, hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(h, g_rccl.AllGather(d_counts + h->world, d_counts, 1, ncclUint64_, (ncclComm_t_)h->comm, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_counts, d_counts, (size_t)h->world * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint64_t maxc = 0;
+    for (int r = 0; r < h->world; r++) maxc = std::max<uint64_t>(maxc, h->h_counts[r]);
+    if (maxc == 0) return HFPF_OK;
+    // the send buffer must hold maxc records (padding is never read by the importers)
+    if (h->ex_send.bytes < maxc * sizeof(EpochRec)) {
+        DevBuf bigger;
+        if ((rc = scratch(h, bigger, maxc * sizeof(EpochRec)))) return rc;
+        if (n_mine) HIPCHK(h, hipMemcpyAsync(bigger.p, h->ex_send.p, n_mine * sizeof(EpochRec), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->ex_send.p));
+        h->device_bytes -= h->ex_send.bytes;
+        h->ex_send = bigger;
+    }
+    if ((rc = scratch(h, h->ex_recv, (size_t)h->world * maxc * sizeof(EpochRec)))) return rc;
+    NCCLCHK(h, g_rccl.AllGather(h->ex_send.p, h->ex_recv.p, maxc * sizeof(EpochRec), ncclChar_, (ncclComm_t_)h->comm, h->stream));
+    for (int r = 0; r < h->world; r++) {
+        if (r == h->rank || h->h_counts[r] == 0) continue;
+        if ((rc = epoch_import_locked(h, (const char*)h->ex_recv.p + (size_t)r * maxc * sizeof(EpochRec), h->h_counts[r]))) return rc;
+    }
+    return HFPF_OK;
+}
+
 int clean_locked(hfpf_handle* h)
 {
     Tables& t = h->t;
     hipStream_t s = h->stream;
-    int rc = read_counters(h);
-    if (rc) return rc;
+    int rc;
+    if (h->dist_on && (rc = dist_exchange_locked(h))) return rc;  // collective: every rank cleans at the same schedule point
+    if ((rc = read_counters(h))) return rc;
     if ((rc = check_device_errors(h))) return rc;
     const uint64_t n_occ = std::min<uint64_t>(h->h_ctr[C_OCC], t.max_occ);
     const uint64_t n_normals = h->h_ctr[C_NORMALS];
+    h->occ_exported = n_occ;  // everything occupied so far (locally or imported) has been exchanged
     h->dirty = false;  // state_changed = false, grid.hpp:313
     h->clean_passes++;
 
@@ -605,6 +734,10 @@ int hfpf_destroy(hfpf_handle* h)
     for (DevBuf* b : {&h->sort_tmp, &h->keys_a, &h->keys_b, &h->vals_a, &h->vals_b, &h->rows_dev, &h->probe_a, &h->probe_b, &h->probe_c, &h->probe_d,
                       &h->probe_e, &h->probe_f})
         if (b->p) (void)hipFree(b->p);
+    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->cstats_total})
+        if (b->p) (void)hipFree(b->p);
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t_)h->comm);
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
     for (auto& s : h->stage) {
         if (s.h_pose) (void)hipHostFree(s.h_pose);
         if (s.h_ids) (void)hipHostFree(s.h_ids);
@@ -702,17 +835,11 @@ int hfpf_clean(hfpf_handle* h)
     return clean_locked(h);
 }
 
-int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
+// Shared tail of extract: `stats` / `cstats` are the (possibly merged) sums to finalise.
+static int extract_locked(hfpf_handle* h, const unsigned long long* stats, const unsigned long long* cstats, hfpf_row** rows, uint64_t* n_rows)
 {
-    if (!h || !rows || !n_rows) return HFPF_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(h->mtx);
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    *rows = nullptr;
-    *n_rows = 0;
     Tables& t = h->t;
-    int rc = read_counters(h);
-    if (rc) return rc;
-    if ((rc = check_device_errors(h))) return rc;
+    int rc;
     const uint64_t n = h->h_ctr[C_NORMALS];
     if (n == 0) return HFPF_OK;
     if ((rc = scratch(h, h->keys_a, n * 8))) return rc;
@@ -727,7 +854,7 @@ int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
     const uint64_t nr = h->h_ctr[C_ROWS];
     if (nr == 0) return HFPF_OK;
     if ((rc = scratch(h, h->rows_dev, nr * sizeof(Row)))) return rc;
-    hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, nr, (const uint64_t*)h->keys_b.p,
+    hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, stats, cstats, nr, (const uint64_t*)h->keys_b.p,
                        (const uint32_t*)h->vals_b.p, (Row*)h->rows_dev.p);
     HIPCHK(h, hipGetLastError());
     hfpf_row* host = (hfpf_row*)malloc(nr * sizeof(hfpf_row));
@@ -740,6 +867,131 @@ int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
     }
     *rows = host;
     *n_rows = nr;
+    return HFPF_OK;
+}
+
+int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
+{
+    if (!h || !rows || !n_rows) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    *rows = nullptr;
+    *n_rows = 0;
+    Tables& t = h->t;
+    int rc = read_counters(h);
+    if (rc) return rc;
+    if ((rc = check_device_errors(h))) return rc;
+    const unsigned long long* stats = t.stats;
+    const unsigned long long* cstats = t.cstats;
+    if (h->dist_on) {
+        // Sum the ranks' private partial records (exact integer adds) into scratch; the partials stay intact.
+        // Normal records are replicated, so every rank holds the same n and the same record ids.
+        const uint64_t words = (h->h_ctr[C_NORMALS] + 1) * kStatWords;
+        if ((rc = scratch(h, h->stats_total, words * 8))) return rc;
+        NCCLCHK(h, g_rccl.AllReduce(t.stats, h->stats_total.p, words, ncclUint64_, ncclSum_, (ncclComm_t_)h->comm, h->stream));
+        stats = (const unsigned long long*)h->stats_total.p;
+        if (t.cstats) {
+            const uint64_t cwords = (h->h_ctr[C_NORMALS] + 1) * 4;
+            if ((rc = scratch(h, h->cstats_total, cwords * 8))) return rc;
+            NCCLCHK(h, g_rccl.AllReduce(t.cstats, h->cstats_total.p, cwords, ncclUint64_, ncclSum_, (ncclComm_t_)h->comm, h->stream));
+            cstats = (const unsigned long long*)h->cstats_total.p;
+        }
+    }
+    return extract_locked(h, stats, cstats, rows, n_rows);
+}
+
+int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* dev_cwords, hfpf_row** rows, uint64_t* n_rows)
+{
+    if (!h || !rows || !n_rows || !dev_words) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    *rows = nullptr;
+    *n_rows = 0;
+    int rc = read_counters(h);
+    if (rc) return rc;
+    if ((rc = check_device_errors(h))) return rc;
+    return extract_locked(h, (const unsigned long long*)dev_words, h->t.cstats ? (const unsigned long long*)dev_cwords : nullptr, rows, n_rows);
+}
+
+int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words, const void** dev_cwords, uint64_t* n_cwords)
+{
+    if (!h || !dev_words || !n_words) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = read_counters(h);
+    if (rc) return rc;
+    *dev_words = h->t.stats;
+    *n_words = (h->h_ctr[C_NORMALS] + 1) * kStatWords;
+    if (dev_cwords) *dev_cwords = h->t.cstats;
+    if (n_cwords) *n_cwords = h->t.cstats ? (h->h_ctr[C_NORMALS] + 1) * 4 : 0;
+    return HFPF_OK;
+}
+
+int hfpf_epoch_export(hfpf_handle* h, const void** dev_records, uint64_t* n_records)
+{
+    if (!h || !dev_records || !n_records) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    uint64_t n = 0;
+    int rc = epoch_export_locked(h, &n, 0);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *dev_records = h->ex_send.p;
+    *n_records = n;
+    return HFPF_OK;
+}
+
+int hfpf_epoch_import(hfpf_handle* h, const void* dev_records, uint64_t n_records)
+{
+    if (!h || (!dev_records && n_records)) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = epoch_import_locked(h, dev_records, n_records);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the caller may reuse / free the record buffer
+    h->dirty = true;
+    return HFPF_OK;
+}
+
+int hfpf_dist_unique_id(void* id128)
+{
+    if (!id128) return HFPF_ERR_BAD_ARG;
+    std::string err;
+    if (load_rccl(err)) return fail(nullptr, HFPF_ERR_DIST, "%s", err.c_str());
+    ncclUniqueId_ id;
+    int r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess_) return fail(nullptr, HFPF_ERR_DIST, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    memcpy(id128, &id, sizeof id);
+    return HFPF_OK;
+}
+
+int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128)
+{
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->dist_on) return fail(h, HFPF_ERR_STATE, "hfpf_dist_init called twice");
+    std::string err;
+    if (load_rccl(err)) return fail(h, HFPF_ERR_DIST, "%s", err.c_str());
+    ncclUniqueId_ id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t_ comm = nullptr;
+    NCCLCHK(h, g_rccl.CommInitRank(&comm, world, id, rank));
+    h->comm = comm;
+    h->rank = rank;
+    h->world = world;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_counts, (size_t)(world + 1) * 8, hipHostMallocDefault));
+    h->dist_on = true;
+    return HFPF_OK;
+}
+
+int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, uint64_t bytes)
+{
+    if (!h || !host_dst || !dev_src) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return HFPF_OK;
 }
 

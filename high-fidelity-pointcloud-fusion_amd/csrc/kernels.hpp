@@ -560,7 +560,8 @@ struct Row {  // = hfpf_row
 };
 static_assert(sizeof(Row) == 64, "row is 64 bytes");
 
-__global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const Tables t, const uint64_t n_rows,
+__global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const Tables t, const unsigned long long* __restrict__ stats,
+                                                      const unsigned long long* __restrict__ cstats, const uint64_t n_rows,
                                                       const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                       Row* __restrict__ rows)
 {
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
     const uint64_t nid = vals[j];
     Row r;
     key_coords(keys[j], r.ix, r.iy, r.iz);
-    const long long* s = reinterpret_cast<const long long*>(&t.stats[nid * kStatWords]);
+    const long long* s = reinterpret_cast<const long long*>(&stats[nid * kStatWords]);
     const long long cnt = s[SW_COUNT];
     r.count = (uint32_t)cnt;
     r.nx = t.nv_n[3 * nid];
@@ -600,8 +601,8 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
         r.mean_dist = (float)md;
         r.sd_dist = (float)fmax(vd, 0.0);
         r.rgb = 0;
-        if (t.cstats) {
-            const long long* cs = reinterpret_cast<const long long*>(&t.cstats[nid * 4]);
+        if (cstats) {
+            const long long* cs = reinterpret_cast<const long long*>(&cstats[nid * 4]);
             const uint32_t cr = (uint32_t)(((double)cs[0] * inv) + 0.5);
             const uint32_t cg = (uint32_t)(((double)cs[1] * inv) + 0.5);
             const uint32_t cb = (uint32_t)(((double)cs[2] * inv) + 0.5);
@@ -609,6 +610,83 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
         }
     }
     rows[j] = r;
+}
+
+
+// ---- multi-GPU epoch exchange ----------------------------------------------------------
+// Frames shard across ranks; what must be agreed before a clean pass is the occupancy set and, per cell, the
+// smallest frame id that touched it (the viewpoint latch).  Each rank exports the cells IT occupied since
+// the last exchange and imports everybody else's; normals and registrations are then computed redundantly
+// and deterministically on every rank, while buffers and statistic sums stay private partial state.
+struct __attribute__((aligned(32))) EpochRec {
+    uint64_t key;
+    uint32_t first_frame;
+    float vx, vy, vz;  // viewpoint of that frame (ranks only know their own frames' poses)
+    uint32_t pad[2];
+};
+static_assert(sizeof(EpochRec) == 32, "EpochRec is 32 bytes");
+
+__global__ __launch_bounds__(256) void k_epoch_export(const GridParams g, const Tables t, const uint64_t first, const uint64_t n_occ, EpochRec* __restrict__ out)
+{
+    const uint64_t j = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_occ) return;
+    const uint32_t slot = t.occ_list[j];
+    int32_t x, y, z;
+    slot_coords(g, t, slot, x, y, z);
+    EpochRec r;
+    r.key = make_key(x, y, z);
+    r.first_frame = t.first_frame[slot];
+    r.vx = r.vy = r.vz = 0.f;
+    if (r.first_frame < t.max_frames) {
+        r.vx = t.frame_vp[3 * (uint64_t)r.first_frame];
+        r.vy = t.frame_vp[3 * (uint64_t)r.first_frame + 1];
+        r.vz = t.frame_vp[3 * (uint64_t)r.first_frame + 2];
+    }
+    r.pad[0] = r.pad[1] = 0;
+    out[j - first] = r;
+}
+
+__global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const Tables t, const EpochRec* __restrict__ in, const uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool want = j < n;
+    EpochRec r;
+    r.key = 0;
+    r.first_frame = kNoFrame;
+    r.vx = r.vy = r.vz = 0.f;
+    int32_t x = 0, y = 0, z = 0;
+    if (want) {
+        r = in[j];
+        key_coords(r.key, x, y, z);
+        want = x <= g.dim[0] && y <= g.dim[1] && z <= g.dim[2];  // storage extent is dim+1 (grid.hpp:626)
+    }
+    const uint32_t bidx = want ? brick_index(g, x, y, z) : 0u;
+    const uint32_t b = brick_acquire_wave(t, bidx, want);
+    want = want && b != 0;
+    const uint32_t slot = b * kBrickCells + local_index(x, y, z);
+    bool first = false;
+    if (want) {
+        const unsigned int old = atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
+        first = !(old & 1u);
+        if (first) atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (x & 7)]), 1ull << (((y & 7) << 3) | (z & 7)));
+        if (r.first_frame < t.max_frames) {
+            atomicMin(&t.first_frame[slot], r.first_frame);
+            t.frame_vp[3 * (uint64_t)r.first_frame] = r.vx;  // same value from every exporter
+            t.frame_vp[3 * (uint64_t)r.first_frame + 1] = r.vy;
+            t.frame_vp[3 * (uint64_t)r.first_frame + 2] = r.vz;
+        }
+    }
+    const unsigned long long oi = wave_reserve(&t.ctr[C_OCC], first);
+    if (first) {
+        if (oi < t.max_occ) t.occ_list[oi] = slot;
+        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_add_u64(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, const uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] += src[j];
 }
 
 // Diagnostic: keys of every occupied cell.

@@ -75,7 +75,12 @@ EXPORTS = [
     "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
     "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
     "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
+    "hfpf_dist_unique_id", "hfpf_dist_init", "hfpf_epoch_export", "hfpf_epoch_import", "hfpf_stats_export",
+    "hfpf_extract_with_stats", "hfpf_device_download",
 ]
+
+EPOCH_REC_DTYPE = np.dtype([("key", "<u8"), ("first_frame", "<u4"), ("vx", "<f4"), ("vy", "<f4"), ("vz", "<f4"), ("pad", "<u4", (2,))])
+assert EPOCH_REC_DTYPE.itemsize == 32
 
 
 def build(force=False):
@@ -126,6 +131,13 @@ def lib():
     L.hfpf_probe_normals.argtypes = [vp, u64, vp, vp, vp, vp, vp]
     L.hfpf_probe_project.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
     L.hfpf_probe_trig.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+    L.hfpf_dist_unique_id.argtypes = [vp]
+    L.hfpf_dist_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.hfpf_epoch_export.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.hfpf_epoch_import.argtypes = [vp, vp, u64]
+    L.hfpf_stats_export.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
+    L.hfpf_extract_with_stats.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(u64)]
+    L.hfpf_device_download.argtypes = [vp, vp, vp, u64]
     _lib = L
     return L
 
@@ -164,6 +176,7 @@ class OccupancyGrid:
         c.flags = FLAG_FUSE_COLOR if fuse_color else 0
         c.max_bricks, c.max_log_points, c.max_normals, c.max_frames = max_bricks, max_log_points, max_normals, max_frames
         self.cfg = c
+        self._transport = None
         self._h = C.c_void_p()
         rc = L.hfpf_create(C.byref(c), C.byref(self._h))
         if rc != 0:
@@ -224,16 +237,63 @@ class OccupancyGrid:
         return bool(self._chk(lib().hfpf_is_dirty(self._h)))
 
     def clean(self):
+        """updateThicknessVectors.  With a host-staged transport attached (see hfpf_dist.py) the epoch exchange
+        runs first; with RCCL (dist_init_rccl) the engine does it internally.  Collective across ranks."""
+        if self._transport is not None:
+            self._transport.exchange(self)
         self._chk(lib().hfpf_clean(self._h))
 
-    def extract(self):
-        rows = C.c_void_p()
-        n = C.c_uint64()
-        self._chk(lib().hfpf_extract(self._h, C.byref(rows), C.byref(n)))
+    def _rows_out(self, rows, n):
         out = np.zeros(n.value, dtype=ROW_DTYPE)
         if n.value:
             C.memmove(out.ctypes.data, rows.value, n.value * ROW_DTYPE.itemsize)
             lib().hfpf_free_rows(rows)
+        return out
+
+    def extract(self):
+        if self._transport is not None:
+            return self._transport.merged_extract(self)
+        rows = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(lib().hfpf_extract(self._h, C.byref(rows), C.byref(n)))
+        return self._rows_out(rows, n)
+
+    # -- multi-GPU --
+    def dist_init_rccl(self, rank, world, unique_id):
+        """unique_id: the 128 bytes rank 0 got from dist_unique_id(), broadcast by the launcher."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(lib().hfpf_dist_init(self._h, rank, world, buf))
+
+    def attach_transport(self, transport):
+        self._transport = transport
+
+    def epoch_export(self):
+        """-> (device pointer, n_records) of the 32-byte records of cells occupied since the last exchange."""
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(lib().hfpf_epoch_export(self._h, C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def epoch_import(self, dev_ptr, n_records):
+        self._chk(lib().hfpf_epoch_import(self._h, C.c_void_p(dev_ptr), n_records))
+
+    def stats_export(self):
+        """-> (dev ptr, n_words, colour dev ptr or 0, n_colour_words) of this handle's partial int64 sums."""
+        p, pc = C.c_void_p(), C.c_void_p()
+        n, nc = C.c_uint64(), C.c_uint64()
+        self._chk(lib().hfpf_stats_export(self._h, C.byref(p), C.byref(n), C.byref(pc), C.byref(nc)))
+        return p.value or 0, n.value, pc.value or 0, nc.value
+
+    def extract_with_stats(self, dev_words, dev_cwords=0):
+        rows = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(lib().hfpf_extract_with_stats(self._h, C.c_void_p(dev_words), C.c_void_p(dev_cwords) if dev_cwords else None,
+                                                C.byref(rows), C.byref(n)))
+        return self._rows_out(rows, n)
+
+    def device_download(self, dev_ptr, nbytes, dtype=np.uint8):
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._chk(lib().hfpf_device_download(self._h, _p(out), C.c_void_p(dev_ptr), out.nbytes))
         return out
 
     def download_data(self, cloud_location, metadata):
@@ -324,6 +384,14 @@ class OccupancyGrid:
         s = np.zeros_like(x)
         self._chk(lib().hfpf_probe_trig(self._h, x.size, _p(y), _p(x), _p(a), _p(c), _p(s)))
         return a, c, s
+
+
+def dist_unique_id():
+    buf = (C.c_char * 128)()
+    rc = lib().hfpf_dist_unique_id(buf)
+    if rc != 0:
+        raise HfpfError(rc, lib().hfpf_last_error(None).decode())
+    return bytes(buf)
 
 
 def write_pcd(rows, path):

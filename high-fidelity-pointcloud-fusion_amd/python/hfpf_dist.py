@@ -1,0 +1,138 @@
+"""Rank plumbing for the multi-GPU path: frame sharding, RCCL bootstrap, and a host-staged
+transport over any torch.distributed backend (gloo included) built on the C ABI's transport-free entry points
+(hfpf_epoch_export / hfpf_epoch_import / hfpf_stats_export / hfpf_extract_with_stats).
+
+The data path of a production run is the engine's own RCCL collectives (hfpf_dist_init); the host-staged
+transport exists so the same protocol runs where RCCL cannot (several virtual ranks on one GPU, gloo-only
+boxes) and as a fallback when communicator creation fails.  This module holds host logic only.
+"""
+import numpy as np
+
+EPOCH_REC_BYTES = 32
+
+
+def shard_frame_ids(n_local, rank, world, start=0):
+    """Global frame ids of this rank's local frames [start, start+n_local): interleaved, so that an epoch of E local
+    frames per rank covers the global ids [start*world, (start+E)*world) on every rank (aligned clean points)."""
+    return ((np.arange(start, start + n_local, dtype=np.int64) * world) + rank).astype(np.uint32)
+
+
+def broadcast_bytes(dist, payload, nbytes, src=0):
+    """Broadcast `nbytes` raw bytes from rank `src` (payload may be None elsewhere)."""
+    import torch
+    t = torch.zeros(nbytes, dtype=torch.uint8)
+    if dist.get_rank() == src:
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    dist.broadcast(t, src=src)
+    return bytes(t.numpy().tobytes())
+
+
+def allgather_bytes(dist, local):
+    """Variable-length all-gather of uint8 arrays: returns a list (one per rank, own rank included)."""
+    import torch
+    world = dist.get_world_size()
+    local = np.ascontiguousarray(local, dtype=np.uint8).reshape(-1)
+    n = torch.tensor([local.size], dtype=torch.int64)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    if mx == 0:
+        return [np.zeros(0, np.uint8) for _ in range(world)]
+    pad = torch.zeros(mx, dtype=torch.uint8)
+    if local.size:
+        pad[:local.size] = torch.from_numpy(local.copy())
+    outs = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return [o.numpy()[:s].copy() for o, s in zip(outs, sizes)]
+
+
+def allreduce_words(dist, words):
+    """Sum of uint64 word arrays across ranks with two's-complement wraparound (the engine's sums are int64)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(words, dtype=np.uint64).view(np.int64).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy().view(np.uint64)
+
+
+def init_rccl(grid, dist, hfpf_mod):
+    """Bootstrap the engine's RCCL communicator: rank 0 creates the id, the launcher's process group carries it."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = hfpf_mod.dist_unique_id() if rank == 0 else None
+    uid = broadcast_bytes(dist, uid, 128, src=0)
+    grid.dist_init_rccl(rank, world, uid)
+
+
+class HostStagedTransport:
+    """The epoch exchange and the statistics merge staged through host memory over torch.distributed."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+
+    def exchange(self, grid):
+        ptr, n = grid.epoch_export()
+        mine = grid.device_download(ptr, n * EPOCH_REC_BYTES) if n else np.zeros(0, np.uint8)
+        parts = allgather_bytes(self.dist, mine)
+        foreign = [p for r, p in enumerate(parts) if r != self.rank and p.size]
+        if foreign:
+            buf = np.concatenate(foreign)
+            dev = grid.device_alloc(buf.nbytes)
+            grid.device_upload(dev, buf)
+            grid.epoch_import(dev, buf.nbytes // EPOCH_REC_BYTES)
+            grid.device_free(dev)
+
+    def merged_extract(self, grid):
+        p, n, pc, nc = grid.stats_export()
+        total = allreduce_words(self.dist, grid.device_download(p, n * 8, np.uint64))
+        dev = grid.device_alloc(total.nbytes)
+        grid.device_upload(dev, total)
+        devc = 0
+        if nc:
+            totc = allreduce_words(self.dist, grid.device_download(pc, nc * 8, np.uint64))
+            devc = grid.device_alloc(totc.nbytes)
+            grid.device_upload(devc, totc)
+        rows = grid.extract_with_stats(dev, devc)
+        grid.device_free(dev)
+        if devc:
+            grid.device_free(devc)
+        return rows
+
+
+class LocalVirtualRanks:
+    """Several handles on one GPU in one process standing in for ranks (tests): same protocol, device-to-device."""
+
+    def __init__(self, grids):
+        self.grids = grids
+
+    def clean_all(self):
+        exports = [g.epoch_export() for g in self.grids]
+        for i, g in enumerate(self.grids):
+            for j, (ptr, n) in enumerate(exports):
+                if i != j and n:
+                    g.epoch_import(ptr, n)
+        for g in self.grids:
+            g.clean()
+
+    def extract(self, on=0):
+        g0 = self.grids[on]
+        tot = totc = None
+        for g in self.grids:
+            p, n, pc, nc = g.stats_export()
+            w = g.device_download(p, n * 8, np.uint64)
+            tot = w if tot is None else (tot + w)  # uint64 wraparound add
+            if nc:
+                c = g.device_download(pc, nc * 8, np.uint64)
+                totc = c if totc is None else (totc + c)
+        dev = g0.device_alloc(tot.nbytes)
+        g0.device_upload(dev, tot)
+        devc = 0
+        if totc is not None:
+            devc = g0.device_alloc(totc.nbytes)
+            g0.device_upload(devc, totc)
+        rows = g0.extract_with_stats(dev, devc)
+        g0.device_free(dev)
+        if devc:
+            g0.device_free(devc)
+        return rows

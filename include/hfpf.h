@@ -156,6 +156,29 @@ int hfpf_device_alloc(hfpf_handle* h, uint64_t bytes, void** dev_ptr);
 int hfpf_device_free(hfpf_handle* h, void* dev_ptr);
 int hfpf_device_upload(hfpf_handle* h, void* dev_dst, const void* host_src, uint64_t bytes);
 
+
+/* ---- multi-GPU (one handle per GPU, one process per GPU) ----------------------------------------------
+ * The reference is single-process; sharding follows SURVEY.md 8(e): frames (or cameras) are dealt to ranks, each
+ * rank integrates only its own frames with GLOBAL frame ids (hfpf_integrate_device frame_ids), and every rank calls
+ * hfpf_clean / hfpf_extract at the same points of the schedule (they become collectives).  At a clean the ranks
+ * exchange the cells they occupied since the last clean (key, smallest frame id, its viewpoint); normals and
+ * registrations are then computed redundantly and identically on every rank; buffers and statistic sums stay
+ * private and are added (exact int64) at extract.  The result is bit-identical to one GPU fusing all frames.
+ *
+ * Transport 1: RCCL.  Rank 0 calls hfpf_dist_unique_id, the launcher broadcasts the 128 bytes (bench.py uses
+ * torch.distributed/gloo, a C++ host would use MPI or a file), every rank calls hfpf_dist_init. */
+int hfpf_dist_unique_id(void* id128);
+int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128);
+/* Transport 2: bring your own.  The same exchange as explicit steps on device buffers (also how tests run several
+ * virtual ranks on one GPU): export -> move the 32-byte records -> import into every other rank -> hfpf_clean;
+ * at the end add the ranks' hfpf_stats_export words and hand the totals to hfpf_extract_with_stats.
+ * Exported pointers are device memory owned by the handle, valid until its next mutating call. */
+int hfpf_epoch_export(hfpf_handle* h, const void** dev_records, uint64_t* n_records);
+int hfpf_epoch_import(hfpf_handle* h, const void* dev_records, uint64_t n_records);
+int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words, const void** dev_cwords, uint64_t* n_cwords);
+int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* dev_cwords, hfpf_row** rows, uint64_t* n_rows);
+int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, uint64_t bytes);
+
 /* ---- measurement: HIP-event timing of the engine's own kernels on the engine's stream ----
  * kernel ids: 0 = integrate.  total_ms / launches accumulate since enable. */
 int hfpf_kernel_timing(hfpf_handle* h, int enable);

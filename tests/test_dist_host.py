@@ -1,0 +1,83 @@
+"""CPU: the host-side rank plumbing of the multi-GPU path under torch.distributed/gloo with world_size 2
+(frame sharding, unique-id broadcast, variable-length record all-gather, wraparound int64 all-reduce)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "high-fidelity-pointcloud-fusion_amd", "python"))
+
+
+def test_shard_frame_ids_partition_each_epoch():
+    import hfpf_dist
+    world, epoch = 4, 150
+    for start in (0, 150, 300):
+        ids = [hfpf_dist.shard_frame_ids(epoch, r, world, start) for r in range(world)]
+        allids = np.sort(np.concatenate(ids))
+        assert np.array_equal(allids, np.arange(start * world, (start + epoch) * world))  # aligned, disjoint, complete
+    assert hfpf_dist.shard_frame_ids(3, 1, 2).tolist() == [1, 3, 5]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        import hfpf_dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # 1. unique-id style broadcast
+        payload = bytes(range(128)) if rank == 0 else None
+        got = hfpf_dist.broadcast_bytes(dist, payload, 128, src=0)
+        assert got == bytes(range(128))
+        # 2. variable-length record exchange (rank 1 has none in round 2)
+        rec = np.zeros(5 + 3 * rank, dtype=np.dtype([("key", "<u8"), ("ff", "<u4"), ("v", "<f4", (3,)), ("pad", "<u4", (2,))]))
+        rec["key"] = (np.arange(rec.size) + 1000 * rank)
+        rec["ff"] = rank
+        parts = hfpf_dist.allgather_bytes(dist, rec.view(np.uint8))
+        assert [p.size // 32 for p in parts] == [5, 8]
+        back = parts[1].view(rec.dtype)
+        assert back["key"].tolist() == list(range(1000, 1008)) and (back["ff"] == 1).all()
+        parts = hfpf_dist.allgather_bytes(dist, rec.view(np.uint8) if rank == 0 else np.zeros(0, np.uint8))
+        assert [p.size for p in parts] == [160, 0]
+        parts = hfpf_dist.allgather_bytes(dist, np.zeros(0, np.uint8))
+        assert all(p.size == 0 for p in parts)
+        # 3. int64 sums travel as uint64 words with wraparound (negative fixed-point sums)
+        words = np.array([5, -7, 2 ** 40, -(2 ** 50)], dtype=np.int64) * (rank + 1)
+        tot = hfpf_dist.allreduce_words(dist, words.view(np.uint64)).view(np.int64)
+        assert tot.tolist() == [15, -21, 3 * 2 ** 40, -3 * 2 ** 50]
+        # 4. max-over-ranks timing reduction as bench.py does it
+        import torch
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 2.0
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def test_gloo_world2_host_transport():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
