@@ -197,6 +197,18 @@ def main():
         pts_per_launch = (K * NPTS) / max(k_launches, 1)
         avg_launch_s = (k_ms / 1e3) / max(k_launches, 1)
         achieved = ALGO_BYTES_PER_POINT * pts_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM-side traffic of k_integrate: PMC counters cannot be read live, so the per-point figures measured by
+        # separate `rocprofv3 --pmc` passes on this same workload (profiles/r01_pmc_k_integrate.*) are scaled to this run.
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_integrate.json")))
+            n_first = min(k_launches, (args.clean_every // max(1, args.frames_per_call)) if args.clean_every else 0)
+            bpp = (n_first * pmc["first_epoch_buffer_only"]["traffic_bytes_per_point"] +
+                   (k_launches - n_first) * pmc["steady_state_after_first_clean"]["traffic_bytes_per_point"]) / max(k_launches, 1)
+            traffic = round(bpp * pts_per_launch)
+            traffic_src = "profiles/r01_pmc_k_integrate.json (FETCH_SIZE corrected + WRITE_SIZE, separate --pmc passes), scaled by points per launch"
+        except Exception:
+            pass
         out = {
             "metric": "Mpts/s fused into 1 mm voxel grid",
             "value": round(value, 3),
@@ -219,7 +231,7 @@ def main():
             "host_path_mpts": round(host_mpts, 3) if host_mpts else None,
             "counters": {k: int(v) for k, v in ctr.items()},
             "roofline": {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT, "launches": int(k_launches),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5)},
         }
