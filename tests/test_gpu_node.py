@@ -1,0 +1,105 @@
+"""GPU: the ROS-free node shell driven like the reference node: Trigger services, subscriber callback, tf lookup,
+first-row rule, clean iteration, process -> files -> clear.  Output files are parsed and compared with the oracle
+run on the same explicit schedule."""
+import numpy as np
+import pytest
+
+import pcd_io
+import scenes
+
+pytestmark = pytest.mark.gpu
+CAPS = dict(max_bricks=60000, max_log_points=4 << 20, max_normals=1 << 20, max_frames=4096)
+
+
+def test_node_state_machine_and_outputs(tmp_path, oracle_mod, hfpf_mod, synth_mod):
+    import hfpf_node
+    sc = scenes.Scene(6, 160, 120, 0.005, clean_every=0)
+    poses = {("base_link", "camera_%d" % f): sc.poses[f] for f in range(sc.n_frames)}
+
+    def tf(target, source):
+        if source == "camera_unknown":
+            raise RuntimeError('"camera_unknown" passed to lookupTransform argument source_frame does not exist.')
+        return poses[(target, source)]
+
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    with hfpf_node.FusionNode(bounding_box=list(sc.bbox), directory_name=str(tmp_path), fusion_frame="base_link", tf_lookup=tf,
+                              clean_period_s=0.0, resolution=sc.resolution, **CAPS) as node:
+        n = sc.W * sc.H
+        # frames before ~start are dropped (node.cpp:331)
+        assert node.publish(sc.frame(0), 1, n, frame_id="camera_0") == 0
+        assert node.stats()["cloud_subscription_started"] == 1
+        rc, ok, _ = node.start()
+        assert rc == 0 and ok
+        for f in range(3):
+            assert node.publish(sc.frame(f), 1, n, frame_id="camera_%d" % f) == 1
+            og.capture(sc.frame(f), sc.poses[f])
+        # tf failure: warn + drop (node.cpp:340-344)
+        assert node.publish(sc.frame(3), 1, n, frame_id="camera_unknown") == 0
+        # an ORGANISED message (height=H) is truncated to its first row (node.cpp:185,190)
+        assert node.publish(sc.frame(3), sc.H, sc.W, frame_id="camera_3") == 1
+        og.capture(sc.frame(3), sc.poses[3], n_points=sc.W)
+        assert node.clean_now() == 1 and node.clean_now() == 0  # cleanGrid runs only when state_changed
+        og.clean()
+        rc, ok, _ = node.stop()
+        assert ok
+        assert node.publish(sc.frame(4), 1, n, frame_id="camera_4") == 0  # stopped
+        node.start()
+        assert node.publish(sc.frame(4), 1, n, frame_id="camera_4") == 1
+        og.capture(sc.frame(4), sc.poses[4])
+        # ~process does NOT clean first in the reference (node.cpp:377-398): frame 4 only updates dependants
+        rc, ok, msg = node.process()
+        assert rc == 0 and ok and "test_cloud.pcd" in msg
+        st = node.stats()
+        assert (st["received"], st["integrated"], st["dropped_not_started"], st["dropped_tf"]) == (8, 5, 2, 1)
+        # the grid was cleared (clearVoxels, node.cpp:438): a second process emits nothing
+        rc, ok, msg = node.process()
+        assert ok and msg.startswith("saved 0 points")
+        # ~reset stops capture but leaves the grid alone (node.cpp:351-359)
+        rc, ok, _ = node.reset()
+        assert ok and node.stats()["started"] == 0 and node.stats()["cloud_subscription_started"] == 0
+    ref = og.extract()
+    hdr, data = pcd_io.read_pcd_ascii(str(tmp_path / "test_cloud.pcd"))
+    header, meta = pcd_io.read_meta_csv(str(tmp_path / "meta.csv"))
+    # the second (empty) process overwrote the files, as the reference would
+    assert hdr["POINTS"] == "0" and meta.shape[0] == 0
+
+
+def test_node_files_match_oracle(tmp_path, oracle_mod, hfpf_mod, synth_mod):
+    import hfpf_node
+    sc = scenes.Scene(5, 160, 120, 0.001, fx=615.0, clean_every=2)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ref = scenes.run(og, sc, "capture")
+    with hfpf_node.FusionNode(bounding_box=list(sc.bbox), directory_name=str(tmp_path), tf_lookup=lambda t, s: sc.poses[int(s)],
+                              resolution=sc.resolution, final_clean_on_process=True, **CAPS) as node:
+        node.start()
+        for f in range(sc.n_frames):
+            assert node.publish(sc.frame(f), 1, sc.W * sc.H, frame_id=str(f)) == 1
+            if sc.clean_every and (f + 1) % sc.clean_every == 0 and f + 1 < sc.n_frames:
+                node.clean_now()
+        rc, ok, msg = node.process()  # final clean (option) + extract + write + clear
+        assert ok, msg
+    hdr, data = pcd_io.read_pcd_ascii(str(tmp_path / "test_cloud.pcd"))
+    header, meta = pcd_io.read_meta_csv(str(tmp_path / "meta.csv"))
+    assert int(hdr["POINTS"]) == len(ref) == data.shape[0] == meta.shape[0]
+    for j, f in enumerate(("x", "y", "z")):
+        assert np.abs(data[:, j] - ref[f]).max() <= 1e-5
+    for j, f in zip((4, 5, 6), ("nx", "ny", "nz")):
+        assert np.allclose(data[:, j], ref[f], rtol=1e-7, atol=0)  # bit-identical normals, printed with 8 digits
+    assert np.array_equal(meta[:, 6], ref["count"])
+
+
+def test_background_clean_thread(tmp_path, hfpf_mod, synth_mod):
+    """cleanGrid as a thread (node.cpp:301-325) with a short period instead of sleep(5)."""
+    import time
+    import hfpf_node
+    sc = scenes.Scene(2, 160, 120, 0.005)
+    with hfpf_node.FusionNode(bounding_box=list(sc.bbox), directory_name=str(tmp_path), clean_period_s=0.05, resolution=sc.resolution,
+                              **CAPS) as node:
+        node.start()
+        node.publish(sc.frame(0), 1, sc.W * sc.H)
+        t0 = time.time()
+        while node.stats()["clean_passes"] == 0 and time.time() - t0 < 10:
+            time.sleep(0.02)
+        assert node.stats()["clean_passes"] >= 1
+        rc, ok, msg = node.process()
+        assert ok and not msg.startswith("saved 0 points")
