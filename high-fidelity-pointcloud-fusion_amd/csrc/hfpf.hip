@@ -1070,6 +1070,7 @@ int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)
     out->frames_integrated = h->frames_integrated;
     out->clean_passes = h->clean_passes;
     out->device_bytes = h->device_bytes;
+    out->replay_members = c[C_REPLAY_MEMBER];
     return HFPF_OK;
 }
 

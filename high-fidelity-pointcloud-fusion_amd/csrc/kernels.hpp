@@ -383,7 +383,10 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
             if (cylinder_member(g, F3{p.x, p.y, p.z}, c, n, proj, dist)) stat_delta_add(d, g, proj, c, dist, __float_as_uint(p.w));
             e = t.log_link[e];
         }
-        if (d.v[SW_COUNT]) stat_flush(t, nid, d);
+        if (d.v[SW_COUNT]) {
+            stat_flush(t, nid, d);
+            atomicAdd(&t.ctr[C_REPLAY_MEMBER], (unsigned long long)d.v[SW_COUNT]);
+        }
     }
 }
 

@@ -62,6 +62,7 @@ enum Ctr : int {
     C_DEP_TESTED,
     C_DEP_MEMBER,
     C_ROWS,         // rows valid at extract
+    C_REPLAY_MEMBER, // buffered points that fell inside a cylinder during clean-time replay
     C_PRECHG,       // unoccupied cells whose single dependant changed in the running clean pass
     C_COUNT = 32
 };

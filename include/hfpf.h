@@ -91,6 +91,7 @@ typedef struct hfpf_counters {
     uint64_t frames_integrated;
     uint64_t clean_passes;
     uint64_t device_bytes;      /* HBM allocated by this handle */
+    uint64_t replay_members;    /* buffered points found inside a cylinder when replayed by a clean pass (grid.hpp:418-440) */
 } hfpf_counters;
 
 void hfpf_default_config(hfpf_config* cfg);
