@@ -1028,6 +1028,54 @@ int hfpf_write_meta_csv(const hfpf_row* rows, uint64_t n, const char* path)
     return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
 }
 
+
+// downloadHQ / downloadClassified / download(XYZRGB) (grid.hpp:491-575; only referenced inside `#if 0`, node.cpp:399-437)
+// as one writer over already extracted rows: PointXYZRGB cloud, optional count filter and colour coding.
+int hfpf_write_pcd_xyzrgb(const hfpf_row* rows, uint64_t n, const char* path, uint32_t min_count, int32_t classify_threshold, int32_t white)
+{
+    if (!path || (!rows && n)) return HFPF_ERR_BAD_ARG;
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < n; i++) kept += rows[i].count >= min_count ? 1 : 0;  // `if(data->count<threshold) continue;` grid.hpp:561
+    FILE* f = fopen(path, "w");
+    if (!f) return HFPF_ERR_IO;
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n");
+    fprintf(f, "WIDTH %llu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %llu\nDATA ascii\n", (unsigned long long)kept, (unsigned long long)kept);
+    for (uint64_t i = 0; i < n; i++) {
+        const hfpf_row& r = rows[i];
+        if (r.count < min_count) continue;
+        uint32_t rgb = white ? 0x00FFFFFFu : r.rgb;                                                // pt.r=g=b=255, grid.hpp:527-529,558-560
+        if (classify_threshold >= 0 && (int64_t)r.count > (int64_t)classify_threshold) rgb = 0x00FF0000u;  // g=b=0, grid.hpp:530-534
+        fprintf(f, "%.8g %.8g %.8g %u\n", r.x, r.y, r.z, rgb);
+    }
+    const bool ok = !ferror(f);
+    return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
+}
+
+// Same fields as hfpf_write_pcd with DATA binary (40 bytes/point): for outputs where ASCII formatting would dominate.
+int hfpf_write_pcd_binary(const hfpf_row* rows, uint64_t n, const char* path)
+{
+    if (!path || (!rows && n)) return HFPF_ERR_BAD_ARG;
+    FILE* f = fopen(path, "wb");
+    if (!f) return HFPF_ERR_IO;
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb normal_x normal_y normal_z curvature\n");
+    fprintf(f, "SIZE 4 4 4 4 4 4 4 4\nTYPE F F F U F F F F\nCOUNT 1 1 1 1 1 1 1 1\n");
+    fprintf(f, "WIDTH %llu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %llu\nDATA binary\n", (unsigned long long)n, (unsigned long long)n);
+    std::vector<char> buf;
+    buf.reserve(32 * 4096);
+    for (uint64_t i = 0; i < n; i++) {
+        const hfpf_row& r = rows[i];
+        const float zero = 0.f;
+        const void* fields[8] = {&r.x, &r.y, &r.z, &r.rgb, &r.nx, &r.ny, &r.nz, &zero};
+        for (int k = 0; k < 8; k++) buf.insert(buf.end(), (const char*)fields[k], (const char*)fields[k] + 4);
+        if (buf.size() >= 32 * 4096 || i + 1 == n) {
+            fwrite(buf.data(), 1, buf.size(), f);
+            buf.clear();
+        }
+    }
+    const bool ok = !ferror(f);
+    return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
+}
+
 int hfpf_clear(hfpf_handle* h)
 {
     if (!h) return HFPF_ERR_BAD_ARG;

@@ -409,10 +409,11 @@ __global__ __launch_bounds__(256) void k_dep_count(const Tables t, const uint64_
 __global__ __launch_bounds__(256) void k_dep_offsets(const Tables t, const uint64_t n_touched)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_touched) return;
-    const uint32_t slot = t.touched_list[j];
-    uint32_t cnt = t.dep_tmp[slot];
-    const unsigned long long off = atomicAdd(&t.ctr[C_DEP], (unsigned long long)cnt);
+    const bool act = j < n_touched;
+    const uint32_t slot = act ? t.touched_list[j] : 0u;
+    uint32_t cnt = act ? t.dep_tmp[slot] : 0u;
+    const unsigned long long off = wave_reserve_n(&t.ctr[C_DEP], cnt);
+    if (!act) return;
     if (cnt > kDepCntMask) {
         atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEPCNT);
         cnt = (uint32_t)kDepCntMask;
@@ -485,14 +486,18 @@ __global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint
 __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_touched) return;
-    const uint32_t slot = t.touched_list[j];
-    const uint64_t info = t.info[slot];
-    const uint32_t old_cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-    const uint64_t old_off = info >> kDepOffShift;
-    const uint32_t add = t.dep_tmp[slot];
-    uint32_t new_cnt = old_cnt + add;
-    const unsigned long long new_off = atomicAdd(&t.ctr[C_DEP], (unsigned long long)new_cnt);
+    const bool act = j < n_touched;
+    uint32_t slot = 0, old_cnt = 0, new_cnt = 0;
+    uint64_t info = 0, old_off = 0;
+    if (act) {
+        slot = t.touched_list[j];
+        info = t.info[slot];
+        old_cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+        old_off = info >> kDepOffShift;
+        new_cnt = old_cnt + t.dep_tmp[slot];
+    }
+    const unsigned long long new_off = wave_reserve_n(&t.ctr[C_DEP], new_cnt);  // one atomic per wave on the hot counter
+    if (!act) return;
     if (new_off + new_cnt > t.max_dep || new_cnt > kDepCntMask) {  // host falls back to a full (compacting) rebuild
         atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
         t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
@@ -517,12 +522,20 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
 __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64_t n_chg)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_chg) return;
-    const uint32_t slot = t.prechg_list[j];
-    const uint64_t info = t.info[slot];
+    const bool act = j < n_chg;
+    uint32_t slot = 0;
+    uint64_t info = 0;
+    bool fresh = false;
+    if (act) {
+        slot = t.prechg_list[j];
+        info = t.info[slot];
+        fresh = ((info >> kDepCntShift) & kDepCntMask) == 0;
+    }
+    const unsigned long long noff = wave_reserve(&t.ctr[C_DEP], fresh);
+    if (!act) return;
     uint64_t off = info >> kDepOffShift;
-    if (((info >> kDepCntShift) & kDepCntMask) == 0) {
-        off = atomicAdd(&t.ctr[C_DEP], 1ull);
+    if (fresh) {
+        off = noff;
         if (off >= t.max_dep) {
             atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEP);
             return;

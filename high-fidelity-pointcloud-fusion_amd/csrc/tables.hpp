@@ -228,6 +228,24 @@ __device__ inline unsigned long long wave_reserve(unsigned long long* ctr, bool 
     return base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Wave-aggregated reservation of a per-lane amount n (0 for idle lanes): one atomic per wave, exclusive
+// prefix sum across the lanes.  Convergent.
+__device__ inline unsigned long long wave_reserve_n(unsigned long long* ctr, uint32_t n)
+{
+    const uint32_t lane = lane_id();
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 63 && total) base = atomicAdd(ctr, (unsigned long long)total);
+    base = __shfl(base, 63);
+    return base + (unsigned long long)(incl - n);
+}
+
 // Wave-reduced counter add (diagnostic counters): convergent.
 __device__ inline void wave_count(unsigned long long* ctr, uint32_t v)
 {

@@ -72,7 +72,7 @@ ROW_DTYPE = np.dtype(
 EXPORTS = [
     "hfpf_default_config", "hfpf_abi_version", "hfpf_create", "hfpf_destroy", "hfpf_last_error", "hfpf_get_dims",
     "hfpf_integrate", "hfpf_integrate_device", "hfpf_is_dirty", "hfpf_clean", "hfpf_extract", "hfpf_free_rows",
-    "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
+    "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_write_pcd_xyzrgb", "hfpf_write_pcd_binary", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
     "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
     "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
     "hfpf_dist_unique_id", "hfpf_dist_init", "hfpf_epoch_export", "hfpf_epoch_import", "hfpf_stats_export",
@@ -118,6 +118,8 @@ def lib():
     L.hfpf_free_rows.restype = None
     L.hfpf_write_pcd.argtypes = [vp, u64, C.c_char_p]
     L.hfpf_write_meta_csv.argtypes = [vp, u64, C.c_char_p]
+    L.hfpf_write_pcd_xyzrgb.argtypes = [vp, u64, C.c_char_p, u32, i32, i32]
+    L.hfpf_write_pcd_binary.argtypes = [vp, u64, C.c_char_p]
     L.hfpf_clear.argtypes = [vp]
     L.hfpf_sync.argtypes = [vp]
     L.hfpf_get_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -406,3 +408,18 @@ def write_meta_csv(rows, path):
     rc = lib().hfpf_write_meta_csv(_p(rows), rows.size, os.fsencode(path))
     if rc != 0:
         raise HfpfError(rc, "write_meta_csv(%s)" % path)
+
+
+def write_pcd_xyzrgb(rows, path, min_count=0, classify_threshold=-1, white=True):
+    """download / downloadHQ(threshold) / downloadClassified of the reference (grid.hpp:491-575)."""
+    rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    rc = lib().hfpf_write_pcd_xyzrgb(_p(rows), rows.size, os.fsencode(path), min_count, classify_threshold, 1 if white else 0)
+    if rc != 0:
+        raise HfpfError(rc, "write_pcd_xyzrgb(%s)" % path)
+
+
+def write_pcd_binary(rows, path):
+    rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    rc = lib().hfpf_write_pcd_binary(_p(rows), rows.size, os.fsencode(path))
+    if rc != 0:
+        raise HfpfError(rc, "write_pcd_binary(%s)" % path)

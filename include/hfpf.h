@@ -140,6 +140,15 @@ int hfpf_write_pcd(const hfpf_row* rows, uint64_t n_rows, const char* path);
 /* <directory_name>/meta.csv (node.cpp:396) with the header string of grid.hpp:462 */
 int hfpf_write_meta_csv(const hfpf_row* rows, uint64_t n_rows, const char* path);
 
+/* The alternate extractors the reference keeps behind `#if 0` (node.cpp:399-437): download(XYZRGB), downloadHQ(threshold)
+ * and downloadClassified (grid.hpp:491-575), as one PointXYZRGB writer over extracted rows.  min_count: rows with
+ * count < min_count are skipped (downloadHQ; 0 keeps all).  white != 0 paints r=g=b=255 as those functions do.
+ * classify_threshold >= 0 paints rows with count > threshold red (downloadClassified uses kGoodPointsThreshold = 100). */
+int hfpf_write_pcd_xyzrgb(const hfpf_row* rows, uint64_t n_rows, const char* path, uint32_t min_count,
+                          int32_t classify_threshold, int32_t white);
+/* test_cloud.pcd with DATA binary (same fields; for the 10k-frame configs where ASCII formatting dominates). */
+int hfpf_write_pcd_binary(const hfpf_row* rows, uint64_t n_rows, const char* path);
+
 /* OccupancyGrid::clearVoxels (grid.hpp:167-183; call site node.cpp:438).  Full reset (documented
  * deviation: the reference leaves stale keys and dependants-only blocks behind). */
 int hfpf_clear(hfpf_handle* h);

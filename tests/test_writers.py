@@ -66,3 +66,29 @@ def test_node_library_exports_and_rejects_bad_bounding_box():
     assert e.value.code == -1 and "bounding_box" in str(e.value)
     with pytest.raises(hfpf.HfpfError):
         hfpf_node.FusionNode(bounding_box=[0, 1, 0, 1, 0])
+
+
+def test_alternate_extractors_and_binary_pcd(tmp_path, hfpf_mod, oracle_mod, synth_mod):
+    """downloadHQ(threshold) / downloadClassified (grid.hpp:514-575) and the binary PCD variant."""
+    sc = scenes.Scene(4, 96, 72, 0.005, clean_every=2)
+    g = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    rows = scenes.run(g, sc, "capture")
+    thr = 2
+    hq = str(tmp_path / "hq.pcd")
+    hfpf_mod.write_pcd_xyzrgb(rows, hq, min_count=thr)  # downloadHQ(cloud, 2): count >= 2, white
+    hdr, data = pcd_io.read_pcd_ascii(hq)
+    keep = rows["count"] >= thr
+    assert hdr["FIELDS"] == "x y z rgb" and int(hdr["POINTS"]) == keep.sum() == data.shape[0]
+    assert np.allclose(data[:, 0], rows["x"][keep], rtol=1e-7) and (data[:, 3] == 0xFFFFFF).all()
+    cl = str(tmp_path / "cl.pcd")
+    hfpf_mod.write_pcd_xyzrgb(rows, cl, classify_threshold=1)  # downloadClassified with threshold 1
+    hdr, data = pcd_io.read_pcd_ascii(cl)
+    assert data.shape[0] == len(rows)
+    assert np.array_equal(data[:, 3] == 0xFF0000, rows["count"] > 1) and np.array_equal(data[:, 3] == 0xFFFFFF, rows["count"] <= 1)
+    b = str(tmp_path / "b.pcd")
+    hfpf_mod.write_pcd_binary(rows, b)
+    raw = open(b, "rb").read()
+    head, _, body = raw.partition(b"DATA binary\n")
+    assert b"POINTS %d" % len(rows) in head and len(body) == 32 * len(rows)
+    arr = np.frombuffer(body, dtype=np.float32).reshape(-1, 8)
+    assert np.array_equal(arr[:, 0], rows["x"]) and np.array_equal(arr[:, 4], rows["nx"]) and (arr[:, 7] == 0).all()
