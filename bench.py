@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--clean-every", type=int, default=150)
     ap.add_argument("--frames-per-call", type=int, default=50)
-    ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--host-path-frames", type=int, default=20, help="frames also pushed through the host-buffer entry point")
     args = ap.parse_args()
     global W, H, NPTS, BBOX, RES
