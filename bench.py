@@ -122,11 +122,11 @@ def main():
     transport = "none"
     if world > 1:
         import hfpf_dist
-        try:  # data path = the engine's own RCCL collectives over xGMI
-            hfpf_dist.init_rccl(grid, dist, hfpf)
+        ok, why = hfpf_dist.init_rccl(grid, dist, hfpf)  # data path = the engine's own RCCL collectives over xGMI
+        if ok:
             transport = "rccl"
-        except hfpf.HfpfError as e:  # keep measuring: stage the same exchange through the launcher's process group
-            log("rank %d: RCCL bootstrap failed (%s); falling back to the host-staged transport" % (rank, e))
+        else:  # keep measuring: stage the same exchange through the launcher's process group (all ranks agree)
+            log("rank %d: RCCL bootstrap failed (%s); falling back to the host-staged transport" % (rank, why))
             grid.attach_transport(hfpf_dist.HostStagedTransport(dist))
             transport = "host-staged (gloo)"
 
@@ -149,6 +149,13 @@ def main():
     log("rank %d: staged %d frames (%.2f GB) in %.1f s (synth %.1f s, upload %.1f s, %d cpus)" % (
         rank, n_gen, n_gen * frame_bytes / 1e9, time.perf_counter() - t_gen, t_synth, t_up, os.cpu_count()))
 
+    clean_time = [0.0]
+
+    def timed_clean():
+        tc = time.perf_counter()
+        grid.clean()  # synchronises (reads device counters)
+        clean_time[0] += time.perf_counter() - tc
+
     def run_stream(n_frames, timed):
         done = 0
         B = max(1, min(args.frames_per_call, (50 * 307200) // NPTS))
@@ -161,8 +168,8 @@ def main():
             grid.integrate_device(dev + done * frame_bytes, b, frame_bytes, NPTS, poses[done:done + b], frame_ids=ids)
             done += b
             if args.clean_every and done % args.clean_every == 0 and done < n_frames:
-                grid.clean()
-        grid.clean()
+                timed_clean()
+        timed_clean()
 
     # ---- warmup (untimed), then reset ----
     if Wm > 0:
@@ -176,6 +183,7 @@ def main():
     if dist is not None:
         dist.barrier()
     grid.sync()
+    clean_time[0] = 0.0
     t0 = time.perf_counter()
     run_stream(K, True)
     grid.sync()
@@ -238,11 +246,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 index/transform, f32 geometry, i64 fixed-point sums",
+            "dtype": "f64",
+            "dtype_detail": "f64 SE(3) transform and voxel index, f32 projection/plane-fit geometry, int64 fixed-point statistic sums",
             "data": "synthetic",
             "config": {"workload": "%s: %s, clean every %d frames + final clean" % (wl["name"], wl["desc"] % K, args.clean_every),
                        "points_per_step": NPTS, "frames_per_call": args.frames_per_call, "parallelism": "one camera stream per GPU, %d rank(s), transport %s" % (world, transport)},
             "extract_s": round(extract_s, 5),
+            "clean_s": round(clean_time[0], 5),  # host time inside hfpf_clean during the timed region (includes draining queued integrates)
             "rows_extracted": int(len(rows)),
             "integrate_kernel_mpts": round(K * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,
             "host_path_mpts": round(host_mpts, 3) if host_mpts else None,

@@ -971,6 +971,7 @@ int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128)
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->dist_on) return fail(h, HFPF_ERR_STATE, "hfpf_dist_init called twice");
+    if (h->h_counts) { (void)hipHostFree(h->h_counts); h->h_counts = nullptr; }
     std::string err;
     if (load_rccl(err)) return fail(h, HFPF_ERR_DIST, "%s", err.c_str());
     ncclUniqueId_ id;
@@ -982,6 +983,19 @@ int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128)
     h->world = world;
     HIPCHK(h, hipHostMalloc((void**)&h->h_counts, (size_t)(world + 1) * 8, hipHostMallocDefault));
     h->dist_on = true;
+    return HFPF_OK;
+}
+
+int hfpf_dist_disable(hfpf_handle* h)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t_)h->comm);
+    h->comm = nullptr;
+    h->dist_on = false;
+    h->rank = 0;
+    h->world = 1;
     return HFPF_OK;
 }
 

@@ -75,7 +75,7 @@ EXPORTS = [
     "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_write_pcd_xyzrgb", "hfpf_write_pcd_binary", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
     "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
     "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
-    "hfpf_dist_unique_id", "hfpf_dist_init", "hfpf_epoch_export", "hfpf_epoch_import", "hfpf_stats_export",
+    "hfpf_dist_unique_id", "hfpf_dist_init", "hfpf_dist_disable", "hfpf_epoch_export", "hfpf_epoch_import", "hfpf_stats_export",
     "hfpf_extract_with_stats", "hfpf_device_download",
 ]
 
@@ -135,6 +135,7 @@ def lib():
     L.hfpf_probe_trig.argtypes = [vp, u64, vp, vp, vp, vp, vp]
     L.hfpf_dist_unique_id.argtypes = [vp]
     L.hfpf_dist_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.hfpf_dist_disable.argtypes = [vp]
     L.hfpf_epoch_export.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.hfpf_epoch_import.argtypes = [vp, vp, u64]
     L.hfpf_stats_export.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
@@ -265,6 +266,9 @@ class OccupancyGrid:
         """unique_id: the 128 bytes rank 0 got from dist_unique_id(), broadcast by the launcher."""
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._chk(lib().hfpf_dist_init(self._h, rank, world, buf))
+
+    def dist_disable(self):
+        self._chk(lib().hfpf_dist_disable(self._h))
 
     def attach_transport(self, transport):
         self._transport = transport

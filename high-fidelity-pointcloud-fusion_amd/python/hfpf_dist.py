@@ -55,12 +55,40 @@ def allreduce_words(dist, words):
     return t.numpy().view(np.uint64)
 
 
+def all_agree(dist, ok):
+    """True only if every rank passes ok=True (MIN all-reduce over the launcher's process group)."""
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def init_rccl(grid, dist, hfpf_mod):
-    """Bootstrap the engine's RCCL communicator: rank 0 creates the id, the launcher's process group carries it."""
+    """Bootstrap the engine's RCCL communicator: rank 0 creates the id, the launcher's process group carries it.
+    Returns (ok, error text).  Either every rank ends up with a communicator or none does."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    uid = hfpf_mod.dist_unique_id() if rank == 0 else None
+    err = ""
+    uid = None
+    if rank == 0:
+        try:
+            uid = hfpf_mod.dist_unique_id()
+        except hfpf_mod.HfpfError as e:
+            err = str(e)
+            uid = bytes(128)
     uid = broadcast_bytes(dist, uid, 128, src=0)
-    grid.dist_init_rccl(rank, world, uid)
+    ok = False
+    if uid != bytes(128):
+        try:
+            grid.dist_init_rccl(rank, world, uid)
+            ok = True
+        except hfpf_mod.HfpfError as e:
+            err = str(e)
+    if not all_agree(dist, ok):
+        if ok:
+            grid.dist_disable()
+            err = "another rank failed to create its communicator"
+        return False, err or "rank 0 could not create a unique id"
+    return True, ""
 
 
 class HostStagedTransport:

@@ -179,6 +179,8 @@ int hfpf_device_upload(hfpf_handle* h, void* dev_dst, const void* host_src, uint
  * torch.distributed/gloo, a C++ host would use MPI or a file), every rank calls hfpf_dist_init. */
 int hfpf_dist_unique_id(void* id128);
 int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128);
+/* Drop the communicator again (e.g. when not every rank managed to create one); clean/extract become local calls. */
+int hfpf_dist_disable(hfpf_handle* h);
 /* Transport 2: bring your own.  The same exchange as explicit steps on device buffers (also how tests run several
  * virtual ranks on one GPU): export -> move the 32-byte records -> import into every other rank -> hfpf_clean;
  * at the end add the ranks' hfpf_stats_export words and hand the totals to hfpf_extract_with_stats.

@@ -14,12 +14,18 @@ def _declared(header):
 
 def test_every_declared_symbol_is_exported(hfpf_mod):
     L = hfpf_mod.lib()
-    names = _declared("hfpf.h") + _declared("hfpf_probe.h")
+    names = [n for n in _declared("hfpf.h") + _declared("hfpf_probe.h") if not n.endswith("_fn")]
     assert len(names) >= 27
     for n in names:
         assert hasattr(L, n), "libhfpf.so does not export %s" % n
     assert sorted(names) == sorted(hfpf_mod.EXPORTS), "python binding EXPORTS out of date with the headers"
     assert L.hfpf_abi_version() == 1
+    import hfpf_node
+    NL = hfpf_node.lib()
+    node_names = [n for n in _declared("hfpf_node.h") if n.startswith("hfpf_node_")]
+    assert sorted(node_names) == sorted(hfpf_node.EXPORTS)
+    for n in node_names:
+        assert hasattr(NL, n), "libhfpf_node.so does not export %s" % n
 
 
 def test_default_config_matches_reference_constants(hfpf_mod):
