@@ -197,6 +197,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     k_ms, k_launches = grid.kernel_time(0)
+    clean_ms, clean_passes = grid.kernel_time(1)
     grid.kernel_timing(False)
     ctr = grid.counters()
 
@@ -208,7 +209,7 @@ def main():
 
     # ---- host-buffer entry point (PCIe-inclusive), informational ----
     host_mpts = None
-    if rank == 0 and host_frames:
+    if rank == 0 and world == 1 and host_frames:
         grid.clear()
         grid.sync()
         th = time.perf_counter()
@@ -252,7 +253,8 @@ def main():
             "config": {"workload": "%s: %s, clean every %d frames + final clean" % (wl["name"], wl["desc"] % K, args.clean_every),
                        "points_per_step": NPTS, "frames_per_call": args.frames_per_call, "parallelism": "one camera stream per GPU, %d rank(s), transport %s" % (world, transport)},
             "extract_s": round(extract_s, 5),
-            "clean_s": round(clean_time[0], 5),  # host time inside hfpf_clean during the timed region (includes draining queued integrates)
+            "clean_s": round(clean_ms / 1e3, 5),  # HIP-event time of the clean passes alone (inside the timed region)
+            "clean_passes": int(clean_passes),
             "rows_extracted": int(len(rows)),
             "integrate_kernel_mpts": round(K * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,
             "host_path_mpts": round(host_mpts, 3) if host_mpts else None,
@@ -262,7 +264,7 @@ def main():
                          "algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT, "launches": int(k_launches),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5)},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen))
         print(json.dumps(out), flush=True)
     grid.device_free(dev)

@@ -105,6 +105,9 @@ struct hfpf_handle {
     // kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending_clean;
+    double t_clean_ms = 0;
+    uint64_t n_clean_timed = 0;
     std::vector<hipEvent_t> ev_free;
     double t_integrate_ms = 0;
     uint64_t n_integrate_launches = 0;
@@ -424,8 +427,17 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
 
 int resolve_timing(hfpf_handle* h)
 {
-    if (h->ev_pending.empty()) return HFPF_OK;
+    if (h->ev_pending.empty() && h->ev_pending_clean.empty()) return HFPF_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& pr : h->ev_pending_clean) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, pr.first, pr.second));
+        h->t_clean_ms += (double)ms;
+        h->n_clean_timed++;
+        h->ev_free.push_back(pr.first);
+        h->ev_free.push_back(pr.second);
+    }
+    h->ev_pending_clean.clear();
     for (auto& pr : h->ev_pending) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, pr.first, pr.second));
@@ -754,6 +766,10 @@ int hfpf_destroy(hfpf_handle* h)
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (auto& pr : h->ev_pending_clean) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     for (auto e : h->ev_free) (void)hipEventDestroy(e);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_log_ctr) (void)hipHostFree(h->h_log_ctr);
@@ -832,7 +848,23 @@ int hfpf_clean(hfpf_handle* h)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    return clean_locked(h);
+    if (!h->timing) return clean_locked(h);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto get = [&](hipEvent_t& e) -> hipError_t {
+        if (!h->ev_free.empty()) {
+            e = h->ev_free.back();
+            h->ev_free.pop_back();
+            return hipSuccess;
+        }
+        return hipEventCreate(&e);
+    };
+    HIPCHK(h, get(e0));
+    HIPCHK(h, get(e1));
+    HIPCHK(h, hipEventRecord(e0, h->stream));  // after every queued integrate: measures the clean pass alone
+    const int rc = clean_locked(h);
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    h->ev_pending_clean.emplace_back(e0, e1);
+    return rc;
 }
 
 // Shared tail of extract: `stats` / `cstats` are the (possibly merged) sums to finalise.
@@ -1197,19 +1229,21 @@ int hfpf_kernel_timing(hfpf_handle* h, int enable)
     if (enable) {
         h->t_integrate_ms = 0;
         h->n_integrate_launches = 0;
+        h->t_clean_ms = 0;
+        h->n_clean_timed = 0;
     }
     return HFPF_OK;
 }
 
 int hfpf_get_kernel_time(hfpf_handle* h, int kernel_id, double* total_ms, uint64_t* launches)
 {
-    if (!h || kernel_id != 0) return HFPF_ERR_BAD_ARG;
+    if (!h || kernel_id < 0 || kernel_id > 1) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = resolve_timing(h);
     if (rc) return rc;
-    if (total_ms) *total_ms = h->t_integrate_ms;
-    if (launches) *launches = h->n_integrate_launches;
+    if (total_ms) *total_ms = kernel_id == 0 ? h->t_integrate_ms : h->t_clean_ms;
+    if (launches) *launches = kernel_id == 0 ? h->n_integrate_launches : h->n_clean_timed;
     return HFPF_OK;
 }
 

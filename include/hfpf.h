@@ -192,7 +192,8 @@ int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* d
 int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, uint64_t bytes);
 
 /* ---- measurement: HIP-event timing of the engine's own kernels on the engine's stream ----
- * kernel ids: 0 = integrate.  total_ms / launches accumulate since enable. */
+ * kernel ids: 0 = k_integrate launches, 1 = whole clean passes (first to last kernel of hfpf_clean, host read-backs
+ * included).  total_ms / launches accumulate since enable. */
 int hfpf_kernel_timing(hfpf_handle* h, int enable);
 int hfpf_get_kernel_time(hfpf_handle* h, int kernel_id, double* total_ms, uint64_t* launches);
 
