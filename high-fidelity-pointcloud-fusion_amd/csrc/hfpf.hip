@@ -292,7 +292,7 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(dep_tmp, h->n_slots, 0, false);
     ALLOC(occ_mask, (t.max_bricks + 1) * 8, 0, false);
     ALLOC(log_pt, t.max_log + 1, 0, false);
-    ALLOC(log_link, t.max_log + 1, 0, false);
+    if (c.flags & HFPF_FLAG_FUSE_COLOR) { ALLOC(log_rgb, t.max_log + 1, 0, false); }
     ALLOC(occ_list, t.max_occ, 0, false);
     ALLOC(nv_key, t.max_normals + 1, 0, false);
     ALLOC(nv_slot, t.max_normals + 1, 0, false);
@@ -612,7 +612,7 @@ int clean_locked(hfpf_handle* h)
     if ((rc = scratch(h, h->keys_a, n_cand * 8))) return rc;
     if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_cand))) return rc;
     hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_cand, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, n_cand, n_normals);
-    const uint64_t n_steps = n_cand * (2ull * (uint64_t)h->g.K + 1ull);
+    const uint64_t n_steps = (((n_cand + 255) / 256) * 256) * (2ull * (uint64_t)h->g.K + 1ull);  // step-major, block-aligned
     hipLaunchKernelGGL(k_register, dim3(blocks_for(n_steps, 256)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand));
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_TOUCHED, 0ull);

@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         if (buf) {
             if (li < t.log_region_cap) {
                 const uint64_t e = log_base + li + 1;
-                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(rgb));
-                t.log_link[e] = slot;
+                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));  // .w: slot until linked, then `next`
+                if (t.log_rgb) t.log_rgb[e] = rgb;
             } else {
                 atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
             }
@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void k_link_log(const Tables t, const LinkRang
     const uint32_t r = blockIdx.y;
     const uint64_t e = (uint64_t)lr.first[r] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e > lr.last[r]) return;
-    const uint32_t slot = t.log_link[e];
-    t.log_link[e] = atomicExch(&t.buf_head[slot], (uint32_t)e);
+    uint32_t* w = reinterpret_cast<uint32_t*>(&t.log_pt[e]) + 3;
+    const uint32_t slot = *w;
+    *w = atomicExch(&t.buf_head[slot], (uint32_t)e);
 }
 
 // 125-bit occupancy stencil around (x,y,z): bit d = ((dx+2)*5 + (dy+2))*5 + (dz+2), the setK table order
@@ -327,11 +328,13 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
 // record ids, which ascend with the canonical key order inside a pass and across passes.
 __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand, const uint64_t base)
 {
+    // step-major mapping: a wave holds 64 key-adjacent voxels at the SAME step, so its targets sit in the same few bricks
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t steps = 2u * (uint32_t)g.K + 1u;
-    const uint64_t r = idx / steps;
-    const int i = (int)(idx % steps) - g.K;
-    bool want = r < n_cand;
+    const uint64_t per_step = ((n_cand + 255) / 256) * 256;  // whole blocks per step keep waves uniform in i
+    const uint64_t r = idx % per_step;
+    const int i = (int)(idx / per_step) - g.K;
+    bool want = r < n_cand && (idx / per_step) < steps;
     uint64_t nid = 0;
     F3 c = {0, 0, 0}, n = {0, 0, 0};
     int32_t xx = 0, yy = 0, zz = 0;
@@ -380,8 +383,8 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
             const float4 p = t.log_pt[e];
             F3 proj;
             double dist;
-            if (cylinder_member(g, F3{p.x, p.y, p.z}, c, n, proj, dist)) stat_delta_add(d, g, proj, c, dist, __float_as_uint(p.w));
-            e = t.log_link[e];
+            if (cylinder_member(g, F3{p.x, p.y, p.z}, c, n, proj, dist)) stat_delta_add(d, g, proj, c, dist, t.log_rgb ? t.log_rgb[e] : 0u);
+            e = __float_as_uint(p.w);  // one 16-byte read per hop: the link travels with the point
         }
         if (d.v[SW_COUNT]) {
             stat_flush(t, nid, d);

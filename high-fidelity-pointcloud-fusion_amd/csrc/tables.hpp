@@ -17,7 +17,7 @@
 //              dep_tmp u32           scratch for the dependant-table rebuild
 //   per brick: occ_mask[8] u64       occupancy bits, one u64 per x-plane (bit = ly*8+lz): the 5x5x5 stencil
 //                                    of grid.hpp:334-349 becomes <= 20 u64 loads.
-//   point log: log_pt float4 (x,y,z,rgb bits) + log_link u32 (slot until linked, then `next`): the
+//   point log: log_pt float4 (x,y,z, w = slot until linked, then `next`) (+ log_rgb u32 with colour fusion): the
 //              reference's per-voxel buffers (grid.hpp:70,211,230) as one append-only array.
 //   normals:   nv_key u64, nv_slot u32, nv_c/nv_n float3, stats[8] i64 per record (stats.hpp)
 //   dependants: reg_occ (slot, stat id) pairs, append-only; dep[] = 32-byte entries grouped per slot,
@@ -100,7 +100,7 @@ struct Tables {
     uint32_t* dep_tmp;
     uint64_t* occ_mask;
     float4* log_pt;
-    uint32_t* log_link;
+    uint32_t* log_rgb;  // NULL unless HFPF_FLAG_FUSE_COLOR
     uint32_t* occ_list;
     uint64_t* nv_key;
     uint32_t* nv_slot;
