@@ -15,6 +15,8 @@
 #include <cstdint>
 #include <cstring>
 
+#include <omp.h>
+
 namespace {
 inline uint64_t splitmix64(uint64_t x)
 {
@@ -120,7 +122,9 @@ void hfpf_synth_frame(uint64_t seed, uint32_t frame_idx, uint32_t W, uint32_t H,
     const double fx = fx_override > 0 ? fx_override : 615.0 * ((double)W / 640.0), fy = fx, cx = W / 2.0, cy = H / 2.0;
     const double o[3] = {pose[3], pose[7], pose[11]};
     uint8_t* base = (uint8_t*)out;
-#pragma omp parallel for schedule(static)
+    // GPU boxes expose every host CPU but grant a small share: cap the team instead of one thread per visible CPU
+    const int n_threads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
+#pragma omp parallel for schedule(static) num_threads(n_threads)
     for (int64_t v = 0; v < (int64_t)H; v++) {
         for (uint32_t u = 0; u < W; u++) {
             const uint64_t pix = (uint64_t)v * W + u;
