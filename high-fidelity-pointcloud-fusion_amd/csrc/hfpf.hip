@@ -623,6 +623,7 @@ int clean_locked(hfpf_handle* h)
     const uint64_t n_pre = std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
     const uint64_t n_chg = std::min<uint64_t>(h->h_ctr[C_PRECHG], t.max_reg);
     const uint64_t n_new = n_reg - h->reg_done;
+    uint64_t inc_touched = 0;
     // incremental update; a conservative space estimate decides whether to compact instead
     bool full = h->h_ctr[C_DEP] + 8 * n_new + n_chg > t.max_dep;
     if (!full) {
@@ -634,6 +635,7 @@ int clean_locked(hfpf_handle* h)
             hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
             hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(n_new, 256)), dim3(256), 0, s, t, h->reg_done, n_reg);
             hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+            inc_touched = n_touched;
         }
         if (n_chg) hipLaunchKernelGGL(k_depinc_pre, dim3(blocks_for(n_chg, 256)), dim3(256), 0, s, t, n_chg);
         HIPCHK(h, hipGetLastError());
@@ -659,9 +661,18 @@ int clean_locked(hfpf_handle* h)
             hipLaunchKernelGGL(k_dep_fill, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
             hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
             HIPCHK(h, hipGetLastError());
+            inc_touched = n_touched;  // superset of the cells touched by this pass; k_replay filters by record id
         }
         if ((rc = read_counters(h))) return rc;
         if ((rc = check_device_errors(h))) return rc;
+    }
+    // buffer replay of the cells that gained registrants in this pass (touched_list is still intact)
+    if (inc_touched) {
+        if (t.cstats)
+            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, inc_touched, n_normals);
+        else
+            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, inc_touched, n_normals);
+        HIPCHK(h, hipGetLastError());
     }
     h->reg_done = n_reg;
     return HFPF_OK;

@@ -4,7 +4,8 @@
 //                         (node.cpp:190-214,251-255,289; grid.hpp:194-277)
 //   K3 k_gate             5x5x5 occupancy count and the >gate test            (grid.hpp:322-352)
 //   K4 k_normal           plane fit on occupied neighbour centres, orientation (grid.hpp:356-398)
-//   K5 k_register         +-K line walk, dependant registration, buffer replay (grid.hpp:403-450)
+//   K5 k_register         +-K line walk, dependant registration (grid.hpp:403-417,443-449)
+//      k_replay           buffer replay of the cells that gained registrants (grid.hpp:418-440)
 //      k_dep_*            rebuild of the per-cell dependant table
 //   K6 k_extract_*        ordered compaction of normal_found voxels            (grid.hpp:463-480)
 #pragma once
@@ -32,7 +33,53 @@ struct FrameLayout {
 // wave-instruction carries 8 whole records, each as 8-byte lanes of one contiguous 64-byte segment
 // (64 requests per round at most, measured 1.8x faster than two segments per record).
 constexpr int kLogRegions = 64;
-constexpr int kQueueStride = 9;  // u64 words per queued pair (7 deltas + record id + rgb); odd stride spreads LDS banks
+
+// Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (7 words + record id + rgb sums)
+// in the wave's LDS queue, then the wave replays the queue with 8 lanes per record, so one wave-instruction
+// carries 8 whole 64-byte records (one memory-side atomic segment each).  Convergent (all 64 lanes must call).
+constexpr int kQueueStride = 11;  // u64 words per queued delta; odd stride spreads LDS banks
+__device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned long long* q, bool member, const StatDelta& d, uint32_t sid)
+{
+    const unsigned long long mm = __ballot(member);
+    if (mm == 0) return;
+    const uint32_t lane = lane_id();
+    const uint32_t n_mem = (uint32_t)__popcll(mm);
+    if (member) {
+        const uint32_t row = (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+        unsigned long long* r = q + row * kQueueStride;
+#pragma unroll
+        for (int w = 0; w < SW_USED; w++) r[w] = (unsigned long long)d.v[w];
+        r[7] = sid;
+        r[8] = (unsigned long long)d.rgb[0];
+        r[9] = (unsigned long long)d.rgb[1];
+        r[10] = (unsigned long long)d.rgb[2];
+    }
+    // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const uint32_t w = lane & 7u;
+        for (uint32_t r0 = 0; r0 < n_mem; r0 += 8) {
+            const uint32_t row = r0 + (lane >> 3);
+            if (row < n_mem && w < SW_USED) {
+                const unsigned long long* r = q + row * kQueueStride;
+                atomicAdd(&t.stats[(uint64_t)r[7] * kStatWords + w], r[w]);
+            }
+        }
+    }
+    if (t.cstats) {  // optional colour fusion: 4 lanes per record, 16 records per wave-instruction
+        const uint32_t w = lane & 3u;
+        for (uint32_t r0 = 0; r0 < n_mem; r0 += 16) {
+            const uint32_t row = r0 + (lane >> 2);
+            if (row < n_mem && w < 3) {
+                const unsigned long long* r = q + row * kQueueStride;
+                atomicAdd(&t.cstats[(uint64_t)r[7] * 4 + w], r[8 + w]);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <bool PACKED16>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
@@ -42,6 +89,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 {
     __shared__ unsigned long long queue[4][64 * kQueueStride];
     __shared__ unsigned int blk_ctr[6];
+    __shared__ BlockReserveScratch brs;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     unsigned long long* q = queue[wave];
@@ -109,10 +157,12 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             if (first) atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (ix & 7)]),
                                 1ull << (((iy & 7) << 3) | (iz & 7)));
         }
-        const unsigned long long oi = wave_reserve(&t.ctr[C_OCC], first);
-        if (first) {
-            if (oi < t.max_occ) t.occ_list[oi] = slot;
-            else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
+        if (__syncthreads_or(first)) {  // block-uniform (tiles are dealt per block): one device atomic per block on the hot counter
+            const unsigned long long oi = block_reserve(&t.ctr[C_OCC], first, brs);
+            if (first) {
+                if (oi < t.max_occ) t.occ_list[oi] = slot;
+                else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
+            }
         }
 
         // buffer while the voxel has no normal (grid.hpp:210-211,230,239); the viewpoint latch (smallest frame
@@ -154,42 +204,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
                     stat_delta_add(d, g, proj, F3{e.cx, e.cy, e.cz}, dist, rgb);
                 }
             }
-            const unsigned long long mm = __ballot(member);
-            if (mm == 0) continue;
-            const uint32_t n_mem = (uint32_t)__popcll(mm);
-            if (member) {
-                const uint32_t row = (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                unsigned long long* r = q + row * kQueueStride;
-#pragma unroll
-                for (int w = 0; w < SW_USED; w++) r[w] = (unsigned long long)d.v[w];
-                r[7] = sid;
-                r[8] = rgb;
-            }
-            // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {
-                const uint32_t w = lane & 7u;
-                for (uint32_t r0 = 0; r0 < n_mem; r0 += 8) {
-                    const uint32_t row = r0 + (lane >> 3);
-                    if (row < n_mem && w < SW_USED) {
-                        const unsigned long long* r = q + row * kQueueStride;
-                        atomicAdd(&t.stats[(uint64_t)r[7] * kStatWords + w], r[w]);
-                    }
-                }
-            }
-            if (t.cstats) {  // optional colour fusion: 4 lanes per record, 16 records per wave-instruction
-                const uint32_t w = lane & 3u;
-                for (uint32_t r0 = 0; r0 < n_mem; r0 += 16) {
-                    const uint32_t row = r0 + (lane >> 2);
-                    if (row < n_mem && w < 3) {
-                        const unsigned long long* r = q + row * kQueueStride;
-                        atomicAdd(&t.cstats[(uint64_t)r[7] * 4 + w], (r[8] >> (16 - 8 * w)) & 255ull);
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_flush_members(t, q, member, d, sid);
         }
     }
     // block-level reduction of the diagnostics: one device atomic per counter per block
@@ -278,7 +293,8 @@ __global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t
             key = make_key(x, y, z);
         }
     }
-    const unsigned long long ci = wave_reserve(&t.ctr[C_CAND], pass);
+    __shared__ BlockReserveScratch brs;
+    const unsigned long long ci = block_reserve(&t.ctr[C_CAND], pass, brs);
     if (pass) t.cand_key[ci] = key;  // capacity = max_occ >= n_occ
 }
 
@@ -354,7 +370,8 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
     const bool occ = want && (t.info[slot] & kOcc);
     const bool unocc = want && !occ;
 
-    const unsigned long long ri = wave_reserve(&t.ctr[C_REG], occ);
+    __shared__ BlockReserveScratch brs;
+    const unsigned long long ri = block_reserve(&t.ctr[C_REG], occ, brs);
     if (occ) {
         if (ri < t.max_reg) t.reg_occ[ri] = make_uint2(slot, (uint32_t)nid);  // dependants.push_back, grid.hpp:417
         else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
@@ -365,32 +382,97 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         newpre = old == 0u;        // first registration ever on this cell
         chgpre = old <= base;      // first change in THIS pass (ids of this pass are > base): exactly one lane sees it
     }
-    const unsigned long long pi = wave_reserve(&t.ctr[C_PREREG], newpre);
+    const unsigned long long pi = block_reserve(&t.ctr[C_PREREG], newpre, brs);
     if (newpre) {
         if (pi < t.max_reg) t.prereg_list[pi] = slot;
         else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
     }
-    const unsigned long long ci = wave_reserve(&t.ctr[C_PRECHG], chgpre);
+    const unsigned long long ci = block_reserve(&t.ctr[C_PRECHG], chgpre, brs);
     if (chgpre) {
         if (ci < t.max_reg) t.prechg_list[ci] = slot;
         else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
     }
-    if (occ) {  // replay the cell's buffered points through this voxel's cylinder (grid.hpp:418-440)
-        StatDelta d;
-        stat_delta_zero(d);
-        uint32_t e = t.buf_head[slot];
-        while (e) {
-            const float4 p = t.log_pt[e];
-            F3 proj;
-            double dist;
-            if (cylinder_member(g, F3{p.x, p.y, p.z}, c, n, proj, dist)) stat_delta_add(d, g, proj, c, dist, t.log_rgb ? t.log_rgb[e] : 0u);
-            e = __float_as_uint(p.w);  // one 16-byte read per hop: the link travels with the point
-        }
-        if (d.v[SW_COUNT]) {
-            stat_flush(t, nid, d);
-            atomicAdd(&t.ctr[C_REPLAY_MEMBER], (unsigned long long)d.v[SW_COUNT]);
+}
+
+// K5b: buffer replay (grid.hpp:418-440), cell-centric.  The reference replays a cell's buffer once per voxel that
+// registers on it; here one thread walks the chain of a touched cell ONCE and tests every buffered point against all
+// of the cell's registrants of this pass (dependant entries with record id > base), four at a time in registers.
+// Random 16-byte chain reads are the cost (sector amplification makes them HBM-bound), so reading each entry once
+// instead of once per registrant is the lever.  Runs after the dependant table has been updated.
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint64_t n_touched, const uint64_t base)
+{
+    __shared__ unsigned long long queue[4][64 * kQueueStride];
+    unsigned long long* q = queue[threadIdx.x >> 6];
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t slot = 0, cnt = 0, head = 0;
+    uint64_t off = 0;
+    if (j < n_touched) {
+        slot = t.touched_list[j];
+        const uint64_t info = t.info[slot];
+        if (info & kOcc) {  // only occupied cells have a buffer
+            cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+            off = info >> kDepOffShift;
+            head = t.buf_head[slot];
+            if (head == 0) cnt = 0;
         }
     }
+    uint32_t replayed = 0;
+    uint32_t next = 0;  // next dependant entry to look at
+    // wave-uniform outer loop: every lane keeps calling the flush helper until all lanes are done
+    while (__ballot(next < cnt) != 0) {
+        constexpr int B = 4;
+        uint32_t sid[B];
+        F3 c[B], n[B];
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            sid[k] = 0;
+            c[k] = F3{0.f, 0.f, 0.f};
+            n[k] = F3{0.f, 0.f, 1.f};
+        }
+        while (next < cnt && m < B) {  // gather up to B registrants of this pass
+            const DepEntry e = t.dep[off + next];
+            next++;
+            if (e.sid > base) {
+#pragma unroll
+                for (int k = 0; k < B; k++)
+                    if (k == m) {
+                        sid[k] = e.sid;
+                        c[k] = F3{e.cx, e.cy, e.cz};
+                        n[k] = F3{e.nx, e.ny, e.nz};
+                    }
+                m++;
+            }
+        }
+        StatDelta d[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) stat_delta_zero(d[k]);
+        if (m > 0) {
+            uint32_t e = head;
+            while (e) {
+                const float4 p = t.log_pt[e];
+                const uint32_t rgb = COLOR ? t.log_rgb[e] : 0u;
+                const F3 pt = F3{p.x, p.y, p.z};
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    if (k < m) {
+                        F3 proj;
+                        double dist;
+                        if (cylinder_member(g, pt, c[k], n[k], proj, dist)) stat_delta_add(d[k], g, proj, c[k], dist, rgb);
+                    }
+                }
+                e = __float_as_uint(p.w);  // one 16-byte read per hop: the link travels with the point
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            const bool member = d[k].v[SW_COUNT] != 0;
+            if (member) replayed += (uint32_t)d[k].v[SW_COUNT];
+            wave_flush_members(t, q, member, d[k], sid[k]);
+        }
+    }
+    wave_count(&t.ctr[C_REPLAY_MEMBER], replayed);
 }
 
 // ---- dependant table rebuild --------------------------------------------------------------------
@@ -405,7 +487,8 @@ __global__ __launch_bounds__(256) void k_dep_count(const Tables t, const uint64_
         slot = reg_slot(t, j, n_reg);
         fresh = atomicAdd(&t.dep_tmp[slot], 1u) == 0u;
     }
-    const unsigned long long ti = wave_reserve(&t.ctr[C_TOUCHED], fresh);
+    __shared__ BlockReserveScratch brs;
+    const unsigned long long ti = block_reserve(&t.ctr[C_TOUCHED], fresh, brs);
     if (fresh) t.touched_list[ti] = slot;  // capacity 2*max_reg >= n_reg + n_pre
 }
 
@@ -482,7 +565,8 @@ __global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint
         slot = t.reg_occ[j].x;
         fresh = atomicAdd(&t.dep_tmp[slot], 1u) == 0u;
     }
-    const unsigned long long ti = wave_reserve(&t.ctr[C_TOUCHED], fresh);
+    __shared__ BlockReserveScratch brs;
+    const unsigned long long ti = block_reserve(&t.ctr[C_TOUCHED], fresh, brs);
     if (fresh) t.touched_list[ti] = slot;
 }
 
@@ -534,7 +618,8 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
         info = t.info[slot];
         fresh = ((info >> kDepCntShift) & kDepCntMask) == 0;
     }
-    const unsigned long long noff = wave_reserve(&t.ctr[C_DEP], fresh);
+    __shared__ BlockReserveScratch brs;
+    const unsigned long long noff = block_reserve(&t.ctr[C_DEP], fresh, brs);
     if (!act) return;
     uint64_t off = info >> kDepOffShift;
     if (fresh) {
@@ -695,7 +780,8 @@ __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const 
             t.frame_vp[3 * (uint64_t)r.first_frame + 2] = r.vz;
         }
     }
-    const unsigned long long oi = wave_reserve(&t.ctr[C_OCC], first);
+    __shared__ BlockReserveScratch brs;
+    const unsigned long long oi = block_reserve(&t.ctr[C_OCC], first, brs);
     if (first) {
         if (oi < t.max_occ) t.occ_list[oi] = slot;
         else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
