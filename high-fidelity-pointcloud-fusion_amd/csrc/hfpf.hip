@@ -325,6 +325,17 @@ int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n)
     return HFPF_OK;
 }
 
+int sort_keys_u32(hfpf_handle* h, uint32_t* in, uint32_t* out, uint64_t n)
+{
+    size_t bytes = 0;
+    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, 32, h->stream));
+    int rc = scratch(h, h->sort_tmp, bytes);
+    if (rc) return rc;
+    bytes = h->sort_tmp.bytes;
+    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, 32, h->stream));
+    return HFPF_OK;
+}
+
 int sort_pairs_u64(hfpf_handle* h, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, uint64_t n)
 {
     size_t bytes = 0;
@@ -407,12 +418,15 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         HIPCHK(h, get(e1));
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
-    if (packed)
-        hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay,
-                           (const double*)s->d_pose, (const uint32_t*)s->d_ids);
-    else
-        hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay,
-                           (const double*)s->d_pose, (const uint32_t*)s->d_ids);
+    const bool color = h->t.cstats != nullptr;
+#define HFPF_LAUNCH_INTEGRATE(P, C)                                                                                                              \
+    hipLaunchKernelGGL((k_integrate<P, C>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay, \
+                       (const double*)s->d_pose, (const uint32_t*)s->d_ids)
+    if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false);
+    else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true);
+    else if (!color) HFPF_LAUNCH_INTEGRATE(false, false);
+    else HFPF_LAUNCH_INTEGRATE(false, true);
+#undef HFPF_LAUNCH_INTEGRATE
     HIPCHK(h, hipGetLastError());
     if (h->timing) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -668,10 +682,14 @@ int clean_locked(hfpf_handle* h)
     }
     // buffer replay of the cells that gained registrants in this pass (touched_list is still intact)
     if (inc_touched) {
+        // a 256-point tile appends consecutive log entries for neighbouring cells, so walking the cells in slot
+        // (brick-major) order lets adjacent lanes share cache lines of the log
+        if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
+        if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched))) return rc;
         if (t.cstats)
-            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
         else
-            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
         HIPCHK(h, hipGetLastError());
     }
     h->reg_done = n_reg;
@@ -739,7 +757,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         int per_cu = 0, cus = 0;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate<true>, 256, 0) != hipSuccess) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate<true, false>, 256, 0) != hipSuccess) per_cu = 4;
         h->integrate_grid = std::max(1, per_cu) * std::max(1, cus);
     }
     if ((rc = alloc_tables(h))) return bail(rc);

@@ -32,13 +32,17 @@ struct FrameLayout {
 // deltas in a per-wave LDS queue and the wave replays the queue with 8 lanes per record, so one
 // wave-instruction carries 8 whole records, each as 8-byte lanes of one contiguous 64-byte segment
 // (64 requests per round at most, measured 1.8x faster than two segments per record).
+#ifndef HFPF_REPLAY_B
+#define HFPF_REPLAY_B 3  // registrants per chain walk held in registers by k_replay
+#endif
 constexpr int kLogRegions = 64;
 
 // Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (7 words + record id + rgb sums)
 // in the wave's LDS queue, then the wave replays the queue with 8 lanes per record, so one wave-instruction
 // carries 8 whole 64-byte records (one memory-side atomic segment each).  Convergent (all 64 lanes must call).
 constexpr int kQueueStride = 11;  // u64 words per queued delta; odd stride spreads LDS banks
-__device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned long long* q, bool member, const StatDelta& d, uint32_t sid)
+template <bool COLOR>
+__device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned long long* q, bool member, const StatDeltaT<COLOR>& d, uint32_t sid)
 {
     const unsigned long long mm = __ballot(member);
     if (mm == 0) return;
@@ -50,9 +54,11 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
 #pragma unroll
         for (int w = 0; w < SW_USED; w++) r[w] = (unsigned long long)d.v[w];
         r[7] = sid;
-        r[8] = (unsigned long long)d.rgb[0];
-        r[9] = (unsigned long long)d.rgb[1];
-        r[10] = (unsigned long long)d.rgb[2];
+        if (COLOR) {
+            r[8] = (unsigned long long)d.rgb[0];
+            r[9] = (unsigned long long)d.rgb[COLOR ? 1 : 0];
+            r[10] = (unsigned long long)d.rgb[COLOR ? 2 : 0];
+        }
     }
     // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -67,7 +73,7 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
             }
         }
     }
-    if (t.cstats) {  // optional colour fusion: 4 lanes per record, 16 records per wave-instruction
+    if (COLOR) {  // optional colour fusion: 4 lanes per record, 16 records per wave-instruction
         const uint32_t w = lane & 3u;
         for (uint32_t r0 = 0; r0 < n_mem; r0 += 16) {
             const uint32_t row = r0 + (lane >> 2);
@@ -81,7 +87,7 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool PACKED16>
+template <bool PACKED16, bool COLOR>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             if (li < t.log_region_cap) {
                 const uint64_t e = log_base + li + 1;
                 t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));  // .w: slot until linked, then `next`
-                if (t.log_rgb) t.log_rgb[e] = rgb;
+                if (COLOR) t.log_rgb[e] = rgb;
             } else {
                 atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
             }
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         for (int o = 32; o > 0; o >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, o));
         for (uint32_t j = 0; j < max_cnt; j++) {
             bool member = false;
-            StatDelta d;
+            StatDeltaT<COLOR> d;
             uint32_t sid = 0;
             if (j < cnt) {
                 const DepEntry e = t.dep[off + j];
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
 // Random 16-byte chain reads are the cost (sector amplification makes them HBM-bound), so reading each entry once
 // instead of once per registrant is the lever.  Runs after the dependant table has been updated.
 template <bool COLOR>
-__global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint64_t n_touched, const uint64_t base)
+__global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint64_t n_touched, const uint64_t base)
 {
     __shared__ unsigned long long queue[4][64 * kQueueStride];
     unsigned long long* q = queue[threadIdx.x >> 6];
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     uint32_t slot = 0, cnt = 0, head = 0;
     uint64_t off = 0;
     if (j < n_touched) {
-        slot = t.touched_list[j];
+        slot = cells[j];  // touched cells in slot (brick-major) order: adjacent lanes walk chains that share cache lines
         const uint64_t info = t.info[slot];
         if (info & kOcc) {  // only occupied cells have a buffer
             cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     uint32_t next = 0;  // next dependant entry to look at
     // wave-uniform outer loop: every lane keeps calling the flush helper until all lanes are done
     while (__ballot(next < cnt) != 0) {
-        constexpr int B = 4;
+        constexpr int B = HFPF_REPLAY_B;
         uint32_t sid[B];
         F3 c[B], n[B];
         int m = 0;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
                 m++;
             }
         }
-        StatDelta d[B];
+        StatDeltaT<COLOR> d[B];
 #pragma unroll
         for (int k = 0; k < B; k++) stat_delta_zero(d[k]);
         if (m > 0) {

@@ -31,20 +31,24 @@ namespace hfpf {
 
 enum StatWord : int { SW_COUNT = 0, SW_S1 = 1, SW_S2 = 4, SW_D = 5, SW_DD = 6, SW_USED = 7 };
 
-struct StatDelta {
+// COLOR = false drops the colour accumulators at compile time (the reference's behaviour and the default path).
+template <bool COLOR>
+struct StatDeltaT {
     long long v[SW_USED];
-    long long rgb[3];
+    long long rgb[COLOR ? 3 : 1];
 };
 
-__device__ __forceinline__ void stat_delta_zero(StatDelta& d)
+template <bool COLOR>
+__device__ __forceinline__ void stat_delta_zero(StatDeltaT<COLOR>& d)
 {
 #pragma unroll
     for (int i = 0; i < SW_USED; i++) d.v[i] = 0;
-    d.rgb[0] = d.rgb[1] = d.rgb[2] = 0;
+    if (COLOR) d.rgb[0] = d.rgb[1] = d.rgb[2] = 0;
 }
 
 // Contribution of one cylinder member.
-__device__ __forceinline__ void stat_delta_add(StatDelta& d, const GridParams& g, F3 proj, F3 c, double dist, uint32_t rgb)
+template <bool COLOR>
+__device__ __forceinline__ void stat_delta_add(StatDeltaT<COLOR>& d, const GridParams& g, F3 proj, F3 c, double dist, uint32_t rgb)
 {
     const double ox = (double)proj.x - (double)c.x;
     const double oy = (double)proj.y - (double)c.y;
@@ -56,21 +60,10 @@ __device__ __forceinline__ void stat_delta_add(StatDelta& d, const GridParams& g
     d.v[SW_S2] += __double2ll_rn(((ox * ox + oy * oy) + oz * oz) * g.s2_scale);
     d.v[SW_D] += __double2ll_rn(dist * g.sd_scale);
     d.v[SW_DD] += __double2ll_rn((dist * dist) * g.sdd_scale);
-    d.rgb[0] += (long long)((rgb >> 16) & 255u);
-    d.rgb[1] += (long long)((rgb >> 8) & 255u);
-    d.rgb[2] += (long long)(rgb & 255u);
-}
-
-__device__ __forceinline__ void stat_flush(const Tables& t, uint64_t sid, const StatDelta& d)
-{
-    unsigned long long* rec = &t.stats[sid * kStatWords];
-#pragma unroll
-    for (int i = 0; i < SW_USED; i++)
-        if (d.v[i] != 0) atomicAdd(rec + i, (unsigned long long)d.v[i]);
-    if (t.cstats) {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            if (d.rgb[i] != 0) atomicAdd(&t.cstats[sid * 4 + i], (unsigned long long)d.rgb[i]);
+    if (COLOR) {
+        d.rgb[0] += (long long)((rgb >> 16) & 255u);
+        d.rgb[COLOR ? 1 : 0] += (long long)((rgb >> 8) & 255u);
+        d.rgb[COLOR ? 2 : 0] += (long long)(rgb & 255u);
     }
 }
 

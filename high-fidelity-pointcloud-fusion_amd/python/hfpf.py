@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(CSRC_DIR, "libhfpf.so")
+LIB_PATH = os.environ.get("HFPF_LIB") or os.path.join(CSRC_DIR, "libhfpf.so")  # HFPF_LIB: A/B builds during tuning
 
 FLAG_FUSE_COLOR = 1
 STATUS = {0: "OK", -1: "BAD_CONFIG", -2: "BAD_ARG", -3: "CAPACITY", -4: "HIP", -5: "STATE", -6: "IO", -7: "DIST"}
