@@ -1083,7 +1083,8 @@ int hfpf_write_pcd(const hfpf_row* rows, uint64_t n, const char* path)
     fprintf(f, "WIDTH %llu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %llu\nDATA ascii\n", (unsigned long long)n, (unsigned long long)n);
     for (uint64_t i = 0; i < n; i++) {
         const hfpf_row& r = rows[i];
-        fprintf(f, "%.8g %.8g %.8g %u %.8g %.8g %.8g 0\n", r.x, r.y, r.z, r.rgb, r.nx, r.ny, r.nz);
+        // the reference never writes rgb (grid.hpp:471-479): a default-constructed PCL point has r=g=b=0, a=255
+        fprintf(f, "%.8g %.8g %.8g %u %.8g %.8g %.8g 0\n", r.x, r.y, r.z, 0xFF000000u | r.rgb, r.nx, r.ny, r.nz);
     }
     const bool ok = !ferror(f);
     return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
@@ -1120,7 +1121,7 @@ int hfpf_write_pcd_xyzrgb(const hfpf_row* rows, uint64_t n, const char* path, ui
         if (r.count < min_count) continue;
         uint32_t rgb = white ? 0x00FFFFFFu : r.rgb;                                                // pt.r=g=b=255, grid.hpp:527-529,558-560
         if (classify_threshold >= 0 && (int64_t)r.count > (int64_t)classify_threshold) rgb = 0x00FF0000u;  // g=b=0, grid.hpp:530-534
-        fprintf(f, "%.8g %.8g %.8g %u\n", r.x, r.y, r.z, rgb);
+        fprintf(f, "%.8g %.8g %.8g %u\n", r.x, r.y, r.z, 0xFF000000u | rgb);
     }
     const bool ok = !ferror(f);
     return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
@@ -1140,7 +1141,8 @@ int hfpf_write_pcd_binary(const hfpf_row* rows, uint64_t n, const char* path)
     for (uint64_t i = 0; i < n; i++) {
         const hfpf_row& r = rows[i];
         const float zero = 0.f;
-        const void* fields[8] = {&r.x, &r.y, &r.z, &r.rgb, &r.nx, &r.ny, &r.nz, &zero};
+        const uint32_t rgba = 0xFF000000u | r.rgb;
+        const void* fields[8] = {&r.x, &r.y, &r.z, &rgba, &r.nx, &r.ny, &r.nz, &zero};
         for (int k = 0; k < 8; k++) buf.insert(buf.end(), (const char*)fields[k], (const char*)fields[k] + 4);
         if (buf.size() >= 32 * 4096 || i + 1 == n) {
             fwrite(buf.data(), 1, buf.size(), f);

@@ -30,6 +30,7 @@ def test_pcd_and_meta_roundtrip(tmp_path, hfpf_mod, oracle_mod, synth_mod):
     for j, f in zip((4, 5, 6), ("nx", "ny", "nz")):
         assert np.allclose(data[:, j], rows[f], rtol=1e-7, atol=0)
     assert (data[:, 7] == 0).all()  # curvature is never written by the reference
+    assert (data[:, 3] == 0xFF000000).all()  # rgb untouched: PCL's default point is r=g=b=0, a=255
     header, m = pcd_io.read_meta_csv(meta)
     assert header == META_HEADER
     assert np.array_equal(m[:, 0], np.arange(len(rows)))  # running id from 0 (grid.hpp:461,478)
@@ -79,12 +80,12 @@ def test_alternate_extractors_and_binary_pcd(tmp_path, hfpf_mod, oracle_mod, syn
     hdr, data = pcd_io.read_pcd_ascii(hq)
     keep = rows["count"] >= thr
     assert hdr["FIELDS"] == "x y z rgb" and int(hdr["POINTS"]) == keep.sum() == data.shape[0]
-    assert np.allclose(data[:, 0], rows["x"][keep], rtol=1e-7) and (data[:, 3] == 0xFFFFFF).all()
+    assert np.allclose(data[:, 0], rows["x"][keep], rtol=1e-7) and (data[:, 3] == 0xFFFFFFFF).all()
     cl = str(tmp_path / "cl.pcd")
     hfpf_mod.write_pcd_xyzrgb(rows, cl, classify_threshold=1)  # downloadClassified with threshold 1
     hdr, data = pcd_io.read_pcd_ascii(cl)
     assert data.shape[0] == len(rows)
-    assert np.array_equal(data[:, 3] == 0xFF0000, rows["count"] > 1) and np.array_equal(data[:, 3] == 0xFFFFFF, rows["count"] <= 1)
+    assert np.array_equal(data[:, 3] == 0xFFFF0000, rows["count"] > 1) and np.array_equal(data[:, 3] == 0xFFFFFFFF, rows["count"] <= 1)
     b = str(tmp_path / "b.pcd")
     hfpf_mod.write_pcd_binary(rows, b)
     raw = open(b, "rb").read()
