@@ -31,7 +31,7 @@ static_assert(sizeof(hfpf_row) == sizeof(Row), "hfpf_row layout");
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // last error of a call that has no handle (create, dist_unique_id)
 
 struct DevBuf {
     void* p = nullptr;

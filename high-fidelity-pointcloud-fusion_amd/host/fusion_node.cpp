@@ -35,7 +35,7 @@ struct hfpf_node {
 };
 
 namespace {
-std::string g_err;
+thread_local std::string g_err;  // last error of hfpf_node_create
 
 int nfail(hfpf_node* n, int code, const std::string& msg)
 {
