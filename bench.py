@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--clean-every", type=int, default=150)
     ap.add_argument("--frames-per-call", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--write-dir", default=None, help="also time writing test_cloud.pcd (ASCII + binary) and meta.csv there")
     ap.add_argument("--host-path-frames", type=int, default=20, help="frames also pushed through the host-buffer entry point")
     args = ap.parse_args()
     global W, H, NPTS, BBOX, RES
@@ -206,6 +207,17 @@ def main():
     rows = grid.extract()
     t3 = time.perf_counter()
     extract_s = t3 - t2
+    write_times = None
+    if rank == 0 and args.write_dir:
+        os.makedirs(args.write_dir, exist_ok=True)
+        tw0 = time.perf_counter()
+        hfpf.write_pcd(rows, os.path.join(args.write_dir, "test_cloud.pcd"))
+        tw1 = time.perf_counter()
+        hfpf.write_meta_csv(rows, os.path.join(args.write_dir, "meta.csv"))
+        tw2 = time.perf_counter()
+        hfpf.write_pcd_binary(rows, os.path.join(args.write_dir, "test_cloud_binary.pcd"))
+        tw3 = time.perf_counter()
+        write_times = {"pcd_ascii_s": round(tw1 - tw0, 4), "meta_csv_s": round(tw2 - tw1, 4), "pcd_binary_s": round(tw3 - tw2, 4)}
 
     # ---- host-buffer entry point (PCIe-inclusive), informational ----
     host_mpts = None
@@ -256,6 +268,7 @@ def main():
             "clean_s": round(clean_ms / 1e3, 5),  # HIP-event time of the clean passes alone (inside the timed region)
             "clean_passes": int(clean_passes),
             "rows_extracted": int(len(rows)),
+            "write_times": write_times,
             "integrate_kernel_mpts": round(K * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,
             "host_path_mpts": round(host_mpts, 3) if host_mpts else None,
             "counters": {k: int(v) for k, v in ctr.items()},

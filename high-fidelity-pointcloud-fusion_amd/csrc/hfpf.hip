@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hfpf.h"
@@ -1072,6 +1073,42 @@ int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, ui
 
 void hfpf_free_rows(hfpf_row* rows) { free(rows); }
 
+
+}  // extern "C" (the helper below is a template)
+
+namespace {
+// Formats rows [0,n) with `fmt_row` on several host threads (one contiguous chunk each) and writes the chunks in
+// order: ASCII formatting, not I/O, dominates the reference's savePCDFileASCII-style outputs.
+template <typename F>
+bool write_rows_parallel(FILE* f, uint64_t n, size_t bytes_per_row_hint, F fmt_row)
+{
+    if (n == 0) return true;
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1, 16), n / 4096 + 1));
+    std::vector<std::string> parts(n_thr);
+    std::vector<std::thread> thr;
+    const uint64_t per = (n + n_thr - 1) / n_thr;
+    for (unsigned t = 0; t < n_thr; t++) {
+        thr.emplace_back([&, t] {
+            const uint64_t a = t * per, b = std::min<uint64_t>(n, a + per);
+            std::string& s = parts[t];
+            if (b > a) s.reserve((size_t)(b - a) * bytes_per_row_hint);
+            char line[256];
+            for (uint64_t i = a; i < b; i++) {
+                const int len = fmt_row(i, line, sizeof line);
+                if (len > 0) s.append(line, (size_t)len);
+            }
+        });
+    }
+    for (auto& t : thr) t.join();
+    for (auto& s : parts)
+        if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
 int hfpf_write_pcd(const hfpf_row* rows, uint64_t n, const char* path)
 {
     if (!path || (!rows && n)) return HFPF_ERR_BAD_ARG;
@@ -1081,12 +1118,12 @@ int hfpf_write_pcd(const hfpf_row* rows, uint64_t n, const char* path)
     fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb normal_x normal_y normal_z curvature\n");
     fprintf(f, "SIZE 4 4 4 4 4 4 4 4\nTYPE F F F U F F F F\nCOUNT 1 1 1 1 1 1 1 1\n");
     fprintf(f, "WIDTH %llu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %llu\nDATA ascii\n", (unsigned long long)n, (unsigned long long)n);
-    for (uint64_t i = 0; i < n; i++) {
+    // the reference never writes rgb (grid.hpp:471-479): a default-constructed PCL point has r=g=b=0, a=255
+    bool ok = write_rows_parallel(f, n, 96, [rows](uint64_t i, char* line, size_t cap) {
         const hfpf_row& r = rows[i];
-        // the reference never writes rgb (grid.hpp:471-479): a default-constructed PCL point has r=g=b=0, a=255
-        fprintf(f, "%.8g %.8g %.8g %u %.8g %.8g %.8g 0\n", r.x, r.y, r.z, 0xFF000000u | r.rgb, r.nx, r.ny, r.nz);
-    }
-    const bool ok = !ferror(f);
+        return snprintf(line, cap, "%.8g %.8g %.8g %u %.8g %.8g %.8g 0\n", r.x, r.y, r.z, 0xFF000000u | r.rgb, r.nx, r.ny, r.nz);
+    });
+    ok = ok && !ferror(f);
     return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
 }
 
@@ -1096,14 +1133,14 @@ int hfpf_write_meta_csv(const hfpf_row* rows, uint64_t n, const char* path)
     FILE* f = fopen(path, "w");
     if (!f) return HFPF_ERR_IO;
     fprintf(f, "Id,sdx,sdy,sdz,mean distance from normal, distance from normal sd, points in cylinder\n");  // grid.hpp:462 verbatim
-    for (uint64_t i = 0; i < n; i++) {
-        const hfpf_row& r = rows[i];  // default ostream float formatting = %g (6 significant digits), grid.hpp:478
-        fprintf(f, "%llu,%g,%g,%g,%g,%g,%d\n", (unsigned long long)i, r.sdx, r.sdy, r.sdz, r.mean_dist, r.sd_dist, (int)r.count);
-    }
-    const bool ok = !ferror(f);
+    // default ostream float formatting = %g (6 significant digits), grid.hpp:478
+    bool ok = write_rows_parallel(f, n, 80, [rows](uint64_t i, char* line, size_t cap) {
+        const hfpf_row& r = rows[i];
+        return snprintf(line, cap, "%llu,%g,%g,%g,%g,%g,%d\n", (unsigned long long)i, r.sdx, r.sdy, r.sdz, r.mean_dist, r.sd_dist, (int)r.count);
+    });
+    ok = ok && !ferror(f);
     return (fclose(f) == 0 && ok) ? HFPF_OK : HFPF_ERR_IO;
 }
-
 
 // downloadHQ / downloadClassified / download(XYZRGB) (grid.hpp:491-575; only referenced inside `#if 0`, node.cpp:399-437)
 // as one writer over already extracted rows: PointXYZRGB cloud, optional count filter and colour coding.

@@ -54,10 +54,10 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
 #pragma unroll
         for (int w = 0; w < SW_USED; w++) r[w] = (unsigned long long)d.v[w];
         r[7] = sid;
-        if (COLOR) {
+        if constexpr (COLOR) {
             r[8] = (unsigned long long)d.rgb[0];
-            r[9] = (unsigned long long)d.rgb[COLOR ? 1 : 0];
-            r[10] = (unsigned long long)d.rgb[COLOR ? 2 : 0];
+            r[9] = (unsigned long long)d.rgb[1];
+            r[10] = (unsigned long long)d.rgb[2];
         }
     }
     // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler

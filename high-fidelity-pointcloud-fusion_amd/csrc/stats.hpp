@@ -43,7 +43,7 @@ __device__ __forceinline__ void stat_delta_zero(StatDeltaT<COLOR>& d)
 {
 #pragma unroll
     for (int i = 0; i < SW_USED; i++) d.v[i] = 0;
-    if (COLOR) d.rgb[0] = d.rgb[1] = d.rgb[2] = 0;
+    if constexpr (COLOR) d.rgb[0] = d.rgb[1] = d.rgb[2] = 0;
 }
 
 // Contribution of one cylinder member.
@@ -60,10 +60,10 @@ __device__ __forceinline__ void stat_delta_add(StatDeltaT<COLOR>& d, const GridP
     d.v[SW_S2] += __double2ll_rn(((ox * ox + oy * oy) + oz * oz) * g.s2_scale);
     d.v[SW_D] += __double2ll_rn(dist * g.sd_scale);
     d.v[SW_DD] += __double2ll_rn((dist * dist) * g.sdd_scale);
-    if (COLOR) {
+    if constexpr (COLOR) {
         d.rgb[0] += (long long)((rgb >> 16) & 255u);
-        d.rgb[COLOR ? 1 : 0] += (long long)((rgb >> 8) & 255u);
-        d.rgb[COLOR ? 2 : 0] += (long long)(rgb & 255u);
+        d.rgb[1] += (long long)((rgb >> 8) & 255u);
+        d.rgb[2] += (long long)(rgb & 255u);
     }
 }
 
