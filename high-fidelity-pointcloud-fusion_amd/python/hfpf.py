@@ -155,6 +155,23 @@ def default_config():
     return c
 
 
+class _RowBuffer:
+    """Owner of one hfpf_extract result (engine-allocated); exposes it to numpy without copying."""
+
+    def __init__(self, ptr, n):
+        self._ptr, self._n = ptr, n
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (self._n,), "typestr": "|V%d" % ROW_DTYPE.itemsize, "descr": ROW_DTYPE.descr, "data": (self._ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            lib().hfpf_free_rows(C.c_void_p(self._ptr))
+        except Exception:
+            pass
+
+
 class OccupancyGrid:
     """Device-resident occupancy grid.  Keyword defaults are the reference's constants."""
 
@@ -247,11 +264,10 @@ class OccupancyGrid:
         self._chk(lib().hfpf_clean(self._h))
 
     def _rows_out(self, rows, n):
-        out = np.zeros(n.value, dtype=ROW_DTYPE)
-        if n.value:
-            C.memmove(out.ctypes.data, rows.value, n.value * ROW_DTYPE.itemsize)
-            lib().hfpf_free_rows(rows)
-        return out
+        """Zero-copy: a numpy view over the engine-owned row buffer; hfpf_free_rows runs when the view is collected."""
+        if not n.value:
+            return np.zeros(0, dtype=ROW_DTYPE)
+        return np.asarray(_RowBuffer(rows.value, n.value))
 
     def extract(self):
         if self._transport is not None:
