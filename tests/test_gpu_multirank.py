@@ -82,3 +82,82 @@ def test_rccl_path_world_size_one(hfpf_mod, synth_mod):
         b.dist_init_rccl(0, 1, hfpf_mod.dist_unique_id())
         got = scenes.run(b, sc, "integrate")
     assert ref.tobytes() == got.tobytes()
+
+
+def _two_proc_worker(rank, world, port, q, scene_kw):
+    """One OS process = one rank (both on GPU 0): own camera stream, global frame ids, host-staged gloo transport."""
+    try:
+        import os
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        root = os.path.dirname(here)
+        for p in (os.path.join(root, "high-fidelity-pointcloud-fusion_amd", "python"), here):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import numpy as np
+        import torch.distributed as dist
+        import hfpf
+        import hfpf_dist
+        import scenes
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sc = scenes.Scene(seed=0xF051 + 7919 * rank, pose_seed=0x5E3 + 104729 * rank, **scene_kw)
+        g = hfpf.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL)
+        g.attach_transport(hfpf_dist.HostStagedTransport(dist))
+        fb = sc.W * sc.H * 16
+        dev = g.device_alloc(fb)
+        for f in range(sc.n_frames):
+            g.device_upload(dev, sc.frame(f))
+            g.integrate_device(dev, 1, fb, sc.W * sc.H, sc.poses[f].reshape(1, 12), frame_ids=hfpf_dist.shard_frame_ids(1, rank, world, f))
+            g.sync()
+            if (f + 1) % sc.clean_every == 0 and f + 1 < sc.n_frames:
+                g.clean()  # collective
+        g.clean()
+        rows = g.extract()  # collective: int64 sums all-reduced over gloo
+        q.put((rank, rows.tobytes()))
+        g.device_free(dev)
+        g.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def test_two_processes_one_stream_each_equal_single_process(hfpf_mod, synth_mod):
+    """bench.py's N>1 shape: one camera stream per rank into one shared grid.  Every rank must end with the rows a single
+    process gets when it is fed both streams interleaved in global frame-id order."""
+    import multiprocessing as mp
+    import socket
+    kw = dict(n_frames=4, W=160, H=120, resolution=0.001, fx=615.0, clean_every=2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_proc_worker, args=(r, 2, port, q, kw)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert not (isinstance(res[r], str)), res[r]
+    assert res[0] == res[1], "ranks disagree on the merged rows"
+    streams = [scenes.Scene(seed=0xF051 + 7919 * r, pose_seed=0x5E3 + 104729 * r, **kw) for r in range(2)]
+    fb = 160 * 120 * 16
+    with hfpf_mod.OccupancyGrid(resolution=0.001, bbox=streams[0].bbox, **SMALL) as one:
+        dev = one.device_alloc(fb)
+        for f in range(kw["n_frames"]):
+            for r in range(2):
+                one.device_upload(dev, streams[r].frame(f))
+                one.integrate_device(dev, 1, fb, 160 * 120, streams[r].poses[f].reshape(1, 12), frame_ids=np.array([f * 2 + r], np.uint32))
+                one.sync()
+            if (f + 1) % kw["clean_every"] == 0 and f + 1 < kw["n_frames"]:
+                one.clean()
+        one.clean()
+        single = one.extract()
+        one.device_free(dev)
+    assert single.tobytes() == res[0], "two processes differ from one process fusing both streams"
