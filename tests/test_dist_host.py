@@ -29,6 +29,63 @@ def _free_port():
     return p
 
 
+class FakeGrid:
+    """numpy stand-in for the transport-free entry points of the C ABI (hfpf_epoch_export / hfpf_epoch_import /
+    hfpf_stats_export / hfpf_extract_with_stats / device_*), so HostStagedTransport runs on CPU under gloo."""
+    REC = np.dtype([("key", "<u8"), ("first_frame", "<u4"), ("vx", "<f4"), ("vy", "<f4"), ("vz", "<f4"), ("pad", "<u4", (2,))])
+
+    def __init__(self):
+        self.cells = {}       # key -> first_frame (replicated after exchange)
+        self.unexported = []  # keys occupied locally since the last exchange
+        self.mem = {}         # fake device memory: handle -> uint8 array
+        self.next = 1000
+        self.stats = np.zeros(0, np.uint64)
+
+    def touch(self, key, frame):
+        if key not in self.cells:
+            self.unexported.append(key)
+            self.cells[key] = frame
+        else:
+            self.cells[key] = min(self.cells[key], frame)
+
+    def _put(self, arr):
+        h = self.next
+        self.next += 1
+        self.mem[h] = np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()
+        return h
+
+    def epoch_export(self):
+        rec = np.zeros(len(self.unexported), self.REC)
+        for i, k in enumerate(self.unexported):
+            rec[i]["key"], rec[i]["first_frame"] = k, self.cells[k]
+        self.unexported = []
+        return self._put(rec), len(rec)
+
+    def epoch_import(self, dev, n):
+        rec = self.mem[dev][: n * 32].view(self.REC)
+        for r in rec:
+            k, f = int(r["key"]), int(r["first_frame"])
+            self.cells[k] = min(self.cells.get(k, f), f)
+
+    def device_alloc(self, nbytes):
+        return self._put(np.zeros(nbytes, np.uint8))
+
+    def device_upload(self, dev, arr):
+        self.mem[dev] = np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()
+
+    def device_download(self, dev, nbytes, dtype=np.uint8):
+        return self.mem[dev][:nbytes].view(dtype).copy()
+
+    def device_free(self, dev):
+        self.mem.pop(dev, None)
+
+    def stats_export(self):
+        return self._put(self.stats), self.stats.size, 0, 0
+
+    def extract_with_stats(self, dev, devc=0):
+        return self.mem[dev].view(np.uint64).copy()
+
+
 def _worker(rank, world, port, q):
     try:
         import torch.distributed as dist
@@ -61,6 +118,23 @@ def _worker(rank, world, port, q):
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert float(t.item()) == 2.0
+        # 5. the real HostStagedTransport over a numpy fake of the engine: two epochs of exchange, then the stats merge
+        tr = hfpf_dist.HostStagedTransport(dist)
+        g = FakeGrid()
+        g.touch(10, 4 + rank)          # both ranks see cell 10; rank 0's frame is smaller
+        g.touch(100 + rank, 7)         # a private cell each
+        tr.exchange(g)
+        assert g.cells == {10: 4, 100: 7, 101: 7}, g.cells
+        assert g.unexported == []
+        if rank == 1:
+            g.touch(200, 9)            # second epoch: only rank 1 finds something new
+        g.touch(10, 50)                # already known everywhere: must not be re-exported
+        tr.exchange(g)
+        assert g.cells == {10: 4, 100: 7, 101: 7, 200: 9}
+        g.stats = (np.array([1, -2, 3], np.int64) * (rank + 1)).view(np.uint64)
+        tot = tr.merged_extract(g).view(np.int64)
+        assert tot.tolist() == [3, -6, 9]
+        assert g.mem.keys() >= set() and all(isinstance(v, np.ndarray) for v in g.mem.values())
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

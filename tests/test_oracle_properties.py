@@ -1,0 +1,75 @@
+"""CPU: hypothesis property tests of the oracle's grid arithmetic ("property" layer)."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+import oracle
+
+RES = st.sampled_from([0.005, 0.002, 0.001, 0.0005, 0.01])
+LO = st.floats(-2.0, 0.0, width=32)
+EXT = st.floats(0.0625, 2.5, width=32)
+
+
+def _grid(res, lo, ext):
+    bbox = (lo[0], lo[0] + ext[0], lo[1], lo[1] + ext[1], lo[2], lo[2] + ext[2])
+    return oracle.OracleGrid(resolution=res, bbox=bbox), bbox
+
+
+@settings(max_examples=60, deadline=None)
+@given(res=RES, lo=st.tuples(LO, LO, LO), ext=st.tuples(EXT, EXT, EXT), seed=st.integers(0, 2 ** 31))
+def test_valid_points_index_inside_storage(res, lo, ext, seed):
+    """validPoints(p) implies 0 <= index <= dim on every axis: the reference allocates dim+1 cells (grid.hpp:626) and
+    indexes them unchecked (grid.hpp:203), so this is what keeps it from writing out of bounds."""
+    g, bbox = _grid(res, lo, ext)
+    (xd, yd, zd), r = g.dims
+    assert r == float(np.float32(res))
+    for a, d in zip(range(3), (xd, yd, zd)):
+        assert d == int((bbox[2 * a + 1] - bbox[2 * a]) / r)
+    rng = np.random.default_rng(seed)
+    mn, mx = np.array(bbox[0::2]), np.array(bbox[1::2])
+    pts = rng.uniform(mn - 0.01, mx + 0.01, size=(512, 3)).astype(np.float32)
+    # add points at and next to the faces
+    faces = np.nextafter(np.float32(mx), np.float32(-10)).astype(np.float32)
+    pts = np.vstack([pts, faces[None, :], np.float32(mx)[None, :], np.float32(mn)[None, :]]).astype(np.float32)
+    idx, valid = g.probe_index(pts)
+    v = idx[valid]
+    assert (v >= 0).all()
+    assert (v[:, 0] <= xd).all() and (v[:, 1] <= yd).all() and (v[:, 2] <= zd).all()
+    g.close()
+
+
+@settings(max_examples=40, deadline=None)
+@given(res=RES, lo=st.tuples(LO, LO, LO), ext=st.tuples(EXT, EXT, EXT), seed=st.integers(0, 2 ** 31))
+def test_cell_centre_maps_back_to_its_cell(res, lo, ext, seed):
+    """getVoxelCenter (grid.hpp:131-135) followed by getVoxelCoords (grid.hpp:630-637) is the identity on valid cells:
+    the i=0 step of the line walk (grid.hpp:403-411) therefore always registers a voxel on itself."""
+    g, bbox = _grid(res, lo, ext)
+    (xd, yd, zd), _ = g.dims
+    if min(xd, yd, zd) < 2:
+        g.close()
+        return
+    rng = np.random.default_rng(seed)
+    cells = np.stack([rng.integers(0, xd, 256), rng.integers(0, yd, 256), rng.integers(0, zd, 256)], 1).astype(np.int32)
+    c = g.probe_center(cells)
+    idx, valid = g.probe_index(c)
+    ok = valid  # centres of cells touching the bbox face can fail the strict bbox test after f32 rounding
+    assert np.array_equal(idx[ok], cells[ok])
+    assert ok.mean() > 0.9
+    g.close()
+
+
+@settings(max_examples=30, deadline=None)
+@given(seed=st.integers(0, 2 ** 31), n=st.integers(1, 64))
+def test_membership_is_rotation_consistent(seed, n):
+    """Points constructed at radial distance r from a line are members iff r < 1 mm (up to f32 rounding at the boundary)."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-0.4, 0.4, size=(n, 3)).astype(np.float32)
+    nn = rng.normal(size=(n, 3))
+    nn = (nn / np.linalg.norm(nn, axis=1, keepdims=True)).astype(np.float32)
+    perp = np.cross(nn, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    rad = rng.uniform(0, 0.002, n)
+    p = (c + perp * rad[:, None] + nn * rng.uniform(-0.01, 0.01, n)[:, None]).astype(np.float32)
+    _, dist = oracle.probe_project(p, c, nn)
+    clear = np.abs(rad - 0.001) > 5e-6
+    assert np.array_equal((dist < 0.001)[clear], (rad < 0.001)[clear])
+    assert np.allclose(dist, rad, atol=2e-6)
