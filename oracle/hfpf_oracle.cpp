@@ -47,6 +47,18 @@
 
 #include "det_math.h"
 
+// -DORACLE_USE_LIBM swaps the three deterministic trig leaves for this machine's libm (sensitivity studies only:
+// tests/test_oracle_build_variants.py measures how many output rows depend on the last ulp of atan2f/cosf/sinf).
+#ifdef ORACLE_USE_LIBM
+#define ORACLE_ATAN2F(y, x) atan2f((y), (x))
+#define ORACLE_COSF(x) cosf((x))
+#define ORACLE_SINF(x) sinf((x))
+#else
+#define ORACLE_ATAN2F(y, x) odm_atan2f((y), (x))
+#define ORACLE_COSF(x) odm_cosf((x))
+#define ORACLE_SINF(x) odm_sinf((x))
+#endif
+
 namespace {
 
 struct V3 {
@@ -129,9 +141,9 @@ inline void compute_roots(const float m[3][3], float roots[3])
     if (q > 0.0f) q = 0.0f;
 
     float rho = sqrtf(-a_over_3);
-    float theta = odm_atan2f(sqrtf(-q), half_b) * s_inv3;
-    float cos_theta = odm_cosf(theta);
-    float sin_theta = odm_sinf(theta);
+    float theta = ORACLE_ATAN2F(sqrtf(-q), half_b) * s_inv3;
+    float cos_theta = ORACLE_COSF(theta);
+    float sin_theta = ORACLE_SINF(theta);
     roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
