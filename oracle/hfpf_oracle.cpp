@@ -66,7 +66,11 @@ struct V3 {
 };
 
 // Eigen fixed-size-3 reduction order: c0 + (c1 + c2).
+#ifdef ORACLE_SUM3_LEFT  // sensitivity study only: plain left-to-right order instead of Eigen's redux tree
+inline float sum3(float a, float b, float c) { return (a + b) + c; }
+#else
 inline float sum3(float a, float b, float c) { return a + (b + c); }
+#endif
 inline float dot3(const V3& a, const V3& b) { return sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
 inline V3 sub3(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 add3(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -193,16 +197,22 @@ inline bool get_normal(const V3* pts, int n, V3& normal)
 {
     if (n < 3) return false;
     float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef ORACLE_PCL_SHIFTED  // sensitivity study only: PCL >= 1.11 accumulates moments of (p - first point)
+    const V3 K = pts[0];
+#else
+    const V3 K = {0.f, 0.f, 0.f};
+#endif
     for (int i = 0; i < n; i++) {
-        accu[0] += pts[i].x * pts[i].x;
-        accu[1] += pts[i].x * pts[i].y;
-        accu[2] += pts[i].x * pts[i].z;
-        accu[3] += pts[i].y * pts[i].y;
-        accu[4] += pts[i].y * pts[i].z;
-        accu[5] += pts[i].z * pts[i].z;
-        accu[6] += pts[i].x;
-        accu[7] += pts[i].y;
-        accu[8] += pts[i].z;
+        const float px = pts[i].x - K.x, py = pts[i].y - K.y, pz = pts[i].z - K.z;
+        accu[0] += px * px;
+        accu[1] += px * py;
+        accu[2] += px * pz;
+        accu[3] += py * py;
+        accu[4] += py * pz;
+        accu[5] += pz * pz;
+        accu[6] += px;
+        accu[7] += py;
+        accu[8] += pz;
     }
     const float fn = (float)n;
     for (int j = 0; j < 9; j++) accu[j] /= fn;

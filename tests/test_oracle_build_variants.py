@@ -81,3 +81,35 @@ def test_sensitivity_to_libm_trig(tmp_path, synth_mod):
     print("libm vs deterministic trig: %d of %d normals differ in some bit (max abs %.2e), %d counts differ" % (bits, len(ref), dn, moved))
     assert dn < 1e-4
     assert moved <= 0.01 * len(ref)
+
+
+def _diff_report(name, got):
+    ref = GOLD["s1mm__rows"]
+    rows = np.frombuffer(got, dtype=ref.dtype)
+    same_set = len(rows) == len(ref) and all(np.array_equal(rows[f], ref[f]) for f in ("ix", "iy", "iz"))
+    if same_set:
+        dn = max(np.abs(rows[f].astype(np.float64) - ref[f]).max() for f in ("nx", "ny", "nz"))
+        moved = int(np.sum(rows["count"] != ref["count"]))
+        dx = max(np.abs(rows[f].astype(np.float64) - ref[f])[rows["count"] == ref["count"]].max() for f in ("x", "y", "z"))
+        print("%s: same voxel set, max normal diff %.2e, %d of %d counts differ, max XYZ diff at equal count %.2e" % (name, dn, moved, len(ref), dx))
+    else:
+        print("%s: emitted voxel set differs (%d vs %d rows)" % (name, len(rows), len(ref)))
+    return rows, same_set
+
+
+def test_sensitivity_to_eigen_reduction_order(tmp_path, synth_mod):
+    """Eigen's fixed-size-3 reductions evaluate c0 + (c1 + c2) (recalled, not verifiable here).  If they were plain
+    left-to-right instead, how much would move?  Only rounding-level effects are acceptable."""
+    got = _run_variant(tmp_path, "sumleft", ["g++", "-std=c++17", "-O3", "-ffp-contract=off", "-DORACLE_SUM3_LEFT", "-fPIC", "-shared"])
+    rows, same = _diff_report("sum order (a+b)+c", got)
+    assert same
+    assert np.sum(rows["count"] != GOLD["s1mm__rows"]["count"]) <= 0.02 * len(rows)
+
+
+def test_sensitivity_to_pcl_covariance_form(tmp_path, synth_mod):
+    """PCL >= 1.11 shifts the moments by the first point; 1.8 (assumed for the reference) does not.  The single-pass f32
+    form cancels catastrophically ~1 m from the origin at 1 mm voxels, so this leaf really is PCL-version dependent:
+    report it, require only that the run completes with plausible output."""
+    got = _run_variant(tmp_path, "shifted", ["g++", "-std=c++17", "-O3", "-ffp-contract=off", "-DORACLE_PCL_SHIFTED", "-fPIC", "-shared"])
+    rows, same = _diff_report("PCL>=1.11 shifted covariance", got)
+    assert len(rows) > 0.9 * len(GOLD["s1mm__rows"])
