@@ -32,6 +32,7 @@ struct GridParams {
     float ball_r;                 // (float)kBballRadius, grid.hpp:35,42
     int32_t K;                    // node.cpp:311
     int32_t gate;                 // grid.hpp:352
+    int32_t cov_shifted;          // 0: PCL <= 1.10 single-pass moments; 1: PCL >= 1.11 moments of (p - first point)
     // fixed-point scales (powers of two) of the order-free statistic sums, see stats.hpp
     double s1_scale, s2_scale, sd_scale, sdd_scale;
 };
@@ -190,13 +191,22 @@ HFPF_HD F3 eigen33_smallest(float c00, float c01, float c02, float c11, float c1
 // Running single-pass f32 moments in neighbour-table order (pcl::computeMeanAndCovarianceMatrix, dense branch).
 struct Moments {
     float a[9];
+    F3 k;  // shift (PCL >= 1.11: the first point; otherwise 0)
+    bool have_k;
     HFPF_HD void clear()
     {
 #pragma unroll
         for (int i = 0; i < 9; i++) a[i] = 0.0f;
+        k = F3{0.f, 0.f, 0.f};
+        have_k = false;
     }
-    HFPF_HD void add(F3 p)
+    HFPF_HD void add(F3 q, bool shifted = false)
     {
+        if (shifted && !have_k) {
+            k = q;
+            have_k = true;
+        }
+        const F3 p = {q.x - k.x, q.y - k.y, q.z - k.z};
         a[0] += p.x * p.x;
         a[1] += p.x * p.y;
         a[2] += p.x * p.z;

@@ -223,6 +223,7 @@ int setup_params(hfpf_handle* h)
     g.ball_r = (float)c.ball_radius;
     g.K = c.K;
     g.gate = c.gate;
+    g.cov_shifted = (c.flags & HFPF_FLAG_PCL_SHIFTED_COV) ? 1 : 0;
     const double B = ((double)c.K + 2.0) * g.res;  // |proj - c| <= |p - c| <= K*res + sqrt(3)*res
     g.s1_scale = std::ldexp(1.0, pow2_exponent_for(B));
     g.s2_scale = std::ldexp(1.0, pow2_exponent_for(B * B));

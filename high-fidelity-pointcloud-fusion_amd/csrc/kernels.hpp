@@ -323,7 +323,7 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
         const bool set = d < 64 ? ((lo >> d) & 1ull) : ((hi >> (d - 64)) & 1ull);
         if (!set) continue;
         const int a = d / 25 - 2, bq = (d / 5) % 5 - 2, c = d % 5 - 2;
-        m.add(voxel_center(g, x + a, y + bq, z + c));  // grid.hpp:364-369
+        m.add(voxel_center(g, x + a, y + bq, z + c), g.cov_shifted != 0);  // grid.hpp:364-369
         total++;
     }
     F3 normal = m.normal(total);
@@ -843,7 +843,7 @@ __global__ void k_probe_normals(const GridParams g, const uint64_t n, const int3
     for (int d = 0; d < 125; d++) {
         const int a = d / 25 - 2, b = (d / 5) % 5 - 2, c = d % 5 - 2;
         if (!occ[125 * i + d] || !valid_coord(g, x + a, y + b, z + c)) continue;
-        m.add(voxel_center(g, x + a, y + b, z + c));
+        m.add(voxel_center(g, x + a, y + b, z + c), g.cov_shifted != 0);
         total++;
     }
     totals_out[i] = total;

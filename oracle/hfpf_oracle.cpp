@@ -193,15 +193,15 @@ inline V3 eigen33_smallest(const float mat[3][3])
 
 // grid.hpp:295-309 getNormal(cloud, normal) -> computeMeanAndCovarianceMatrix (single-pass float
 // moments, accumulated in cloud order) + solvePlaneParameters (grid.hpp:282-293) -> eigen33.
-inline bool get_normal(const V3* pts, int n, V3& normal)
+inline bool get_normal(const V3* pts, int n, V3& normal, bool shifted = false)
 {
     if (n < 3) return false;
     float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef ORACLE_PCL_SHIFTED  // sensitivity study only: PCL >= 1.11 accumulates moments of (p - first point)
-    const V3 K = pts[0];
-#else
-    const V3 K = {0.f, 0.f, 0.f};
+#ifdef ORACLE_PCL_SHIFTED
+    shifted = true;
 #endif
+    // PCL >= 1.11 accumulates the moments of (p - K), K = first point; PCL <= 1.10 (assumed for the reference) uses K = 0
+    const V3 K = shifted ? pts[0] : V3{0.f, 0.f, 0.f};
     for (int i = 0; i < n; i++) {
         const float px = pts[i].x - K.x, py = pts[i].y - K.y, pz = pts[i].z - K.z;
         accu[0] += px * px;
@@ -272,6 +272,7 @@ struct Config {  // mirrored by oracle.py
     double z_clip_max;       // kZmax node.cpp:93
     int32_t order_mode;      // 0 canonical ascending (x,y,z); 1 libstdc++ unordered_set order
     int32_t reserve;         // buffer.reserve(n) on first touch (reference: 1000, grid.hpp:228); 0 = off
+    int32_t pcl_shifted_cov; // 0 = PCL <= 1.10 computeMeanAndCovarianceMatrix (default), 1 = PCL >= 1.11 shifted form
 };
 
 class Oracle {
@@ -511,7 +512,7 @@ public:
                 }
                 V3 normal{0, 0, 0};
                 V3 centroid = voxel_center(x, y, z);
-                get_normal(cloud.data(), total, normal);
+                get_normal(cloud.data(), total, normal, cfg.pcl_shifted_cov != 0);
                 V3 vp = data->viewpoint;
                 V3 dir = normalized3(sub3(vp, centroid));
                 if (dot3(dir, normal) < 0.0f) normal = {normal.x * -1.0f, normal.y * -1.0f, normal.z * -1.0f};
@@ -719,7 +720,7 @@ int32_t horacle_probe_normal(void* h, int32_t x, int32_t y, int32_t z, const uin
         if (o->valid_coord(xx, yy, zz) && occ[d]) cloud.push_back(o->voxel_center(xx, yy, zz));
     }
     V3 nrm{0, 0, 0};
-    if (get_normal(cloud.data(), (int)cloud.size(), nrm)) {
+    if (get_normal(cloud.data(), (int)cloud.size(), nrm, o->cfg.pcl_shifted_cov != 0)) {
         if (vp) {
             V3 dir = normalized3(sub3(V3{vp[0], vp[1], vp[2]}, o->voxel_center(x, y, z)));
             if (dot3(dir, nrm) < 0.0f) nrm = {nrm.x * -1.0f, nrm.y * -1.0f, nrm.z * -1.0f};

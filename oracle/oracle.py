@@ -26,6 +26,7 @@ class Config(C.Structure):
         ("z_clip_max", C.c_double),
         ("order_mode", C.c_int32),
         ("reserve", C.c_int32),
+        ("pcl_shifted_cov", C.c_int32),
     ]
 
 
@@ -95,7 +96,7 @@ def _p(a):
 
 
 def make_config(resolution=0.005, bbox=(-0.8, 1.8, -1.5, 1.5, 0.0, 1.0), k=2, K=3, gate=20, cylinder_radius=0.001,
-                ball_radius=0.015, z_clip=(0.28, 0.6), order_mode=0, reserve=0):
+                ball_radius=0.015, z_clip=(0.28, 0.6), order_mode=0, reserve=0, pcl_shifted_cov=False):
     """Defaults are the reference's constants (node.cpp:91-93,163,311; grid.hpp:34-36,352; launch:7)."""
     c = Config()
     c.resolution = resolution
@@ -105,6 +106,7 @@ def make_config(resolution=0.005, bbox=(-0.8, 1.8, -1.5, 1.5, 0.0, 1.0), k=2, K=
     c.cylinder_radius, c.ball_radius = cylinder_radius, ball_radius
     c.z_clip_min, c.z_clip_max = z_clip
     c.order_mode, c.reserve = order_mode, reserve
+    c.pcl_shifted_cov = 1 if pcl_shifted_cov else 0
     return c
 
 

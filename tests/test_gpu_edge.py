@@ -27,6 +27,7 @@ def _pair(oracle_mod, hfpf_mod, sc, **cfg):
     dict(K=1), dict(K=5), dict(gate=10), dict(gate=40),
     dict(cylinder_radius=0.0005), dict(cylinder_radius=0.003, ball_radius=0.03),
     dict(z_clip=(0.35, 0.5)),
+    dict(pcl_shifted_cov=True),  # plane fit as PCL >= 1.11 computes the covariance
 ])
 def test_non_default_parameters(oracle_mod, hfpf_mod, synth_mod, cfg):
     sc = scenes.Scene(5, 160, 120, 0.001, fx=615.0, clean_every=2)
