@@ -79,6 +79,9 @@ int main(int argc, char** argv)
     if (pnh.getParam("line_half_length", iv)) p.engine.K = iv;
     if (pnh.getParam("device", iv)) p.engine.device = iv;
     if (pnh.getParam("clean_period", v)) p.clean_period_s = v;
+    bool flag;
+    if (pnh.getParam("fuse_color", flag) && flag) p.engine.flags |= HFPF_FLAG_FUSE_COLOR;
+    if (pnh.getParam("pcl_shifted_covariance", flag) && flag) p.engine.flags |= HFPF_FLAG_PCL_SHIFTED_COV;
     Shell shell;
     if (hfpf_node_create(&p, &Shell::lookup, &shell, &shell.node) != HFPF_OK) {
         ROS_FATAL("%s", hfpf_node_last_error(nullptr));
