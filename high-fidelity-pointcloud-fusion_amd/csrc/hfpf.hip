@@ -94,6 +94,14 @@ struct hfpf_handle {
     DevBuf sort_tmp, keys_a, keys_b, vals_a, vals_b, rows_dev, probe_a, probe_b, probe_c, probe_d, probe_e, probe_f;
     unsigned long long* h_ctr = nullptr;  // pinned mirror of the counters
 
+    // two-pass (binned) dependant update (default; HFPF_FLAG_DIRECT_UPDATE switches it off)
+    bool binned = false;
+    bool bin_have_hist = false;   // bin_fill holds the demand of the previous launch
+    double bin_prev_points = 0;   // points presented by that launch (to scale the plan)
+    uint64_t bin_pool = 0;        // entries in bin_pt
+    uint64_t n_bricks_known = 0;  // bricks allocated at the last counter read-back
+    DevBuf bin_pt_buf, bin_rgb_buf;
+
     // multi-GPU: RCCL is resolved at run time so a single-GPU user needs no librccl
     bool dist_on = false;
     int rank = 0, world = 1;
@@ -176,6 +184,7 @@ int read_counters(hfpf_handle* h)
     unsigned long long total = 0;
     for (int r = 0; r < kLogRegions; r++) total += std::min<unsigned long long>(h->h_log_ctr[r * 16], h->t.log_region_cap);
     h->h_ctr[C_LOG] = total;
+    h->n_bricks_known = std::min<uint64_t>(h->h_ctr[C_BRICKS], h->t.max_bricks);
     return HFPF_OK;
 }
 
@@ -251,6 +260,11 @@ int reset_state(hfpf_handle* h)
     if (t.cstats) HIPCHK(h, hipMemsetAsync(t.cstats, 0, (t.max_normals + 1) * 4 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.ctr, 0, C_COUNT * 8, s));
     HIPCHK(h, hipMemsetAsync(t.log_ctr, 0, kLogRegions * 16 * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.bin_fill, 0, (t.max_bricks + 2) * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.bin_off, 0, (t.max_bricks + 2) * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.bin_capb, 0, (t.max_bricks + 2) * 4, s));
+    h->bin_have_hist = false;
+    h->n_bricks_known = 0;
     h->dirty = false;
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
     h->reg_done = 0;
@@ -311,6 +325,10 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(frame_vp, 3 * t.max_frames);
     ALLOC(ctr, C_COUNT);
     ALLOC(log_ctr, kLogRegions * 16);
+    ALLOC(bin_fill, t.max_bricks + 2);
+    ALLOC(bin_off, t.max_bricks + 2);
+    ALLOC(bin_capb, t.max_bricks + 2);
+    h->binned = (c.flags & HFPF_FLAG_DIRECT_UPDATE) == 0;
 #undef ALLOC
     t.log_region_cap = t.max_log / kLogRegions;
     return reset_state(h);
@@ -421,13 +439,55 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
     const bool color = h->t.cstats != nullptr;
-#define HFPF_LAUNCH_INTEGRATE(P, C)                                                                                                              \
-    hipLaunchKernelGGL((k_integrate<P, C>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay, \
+    const bool bin = h->binned;
+    const uint32_t nb = (uint32_t)h->n_bricks_known;
+    if (bin) {
+        // pool for this launch's parked points (+25 % plan slack, +64 per brick)
+        const uint64_t pts = (uint64_t)n_points * n_frames;
+        const uint64_t pool = pts + pts / 3 + 64ull * (nb + 1);
+        if (pool > 0xFFFFFFFFull) return fail(h, HFPF_ERR_BAD_ARG, "integrate: batch too large for the binned update (split the call)");
+        if (h->bin_pool < pool) {
+            int rc2 = scratch(h, h->bin_pt_buf, pool * sizeof(float4));
+            if (rc2) return rc2;
+            if (color && (rc2 = scratch(h, h->bin_rgb_buf, pool * 4))) return rc2;
+            h->bin_pool = pool;
+        }
+        h->t.bin_pt = (float4*)h->bin_pt_buf.p;
+        h->t.bin_rgb = (uint32_t*)h->bin_rgb_buf.p;
+        if (h->bin_have_hist && nb > 0) {
+            const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points));
+            hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, h->stream, h->t, nb, scale);
+            size_t bytes = 0;
+            HIPCHK(h, rocprim::exclusive_scan(nullptr, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), h->stream));
+            int rc2 = scratch(h, h->sort_tmp, bytes);
+            if (rc2) return rc2;
+            bytes = h->sort_tmp.bytes;
+            HIPCHK(h, rocprim::exclusive_scan(h->sort_tmp.p, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), h->stream));
+            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, h->stream, h->t, nb, h->bin_pool);
+        } else {
+            HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, (h->t.max_bricks + 2) * 4, h->stream));  // no plan yet: every lane goes direct, demand is recorded
+        }
+    }
+#define HFPF_LAUNCH_INTEGRATE(P, C, B)                                                                                                              \
+    hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay, \
                        (const double*)s->d_pose, (const uint32_t*)s->d_ids)
-    if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false);
-    else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true);
-    else if (!color) HFPF_LAUNCH_INTEGRATE(false, false);
-    else HFPF_LAUNCH_INTEGRATE(false, true);
+    if (!bin) {
+        if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, false);
+        else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, false);
+        else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, false);
+        else HFPF_LAUNCH_INTEGRATE(false, true, false);
+    } else {
+        if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, true);
+        else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, true);
+        else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, true);
+        else HFPF_LAUNCH_INTEGRATE(false, true, true);
+        if (nb > 0 && h->bin_have_hist) {
+            if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
+            else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
+        }
+        h->bin_have_hist = true;
+        h->bin_prev_points = (double)n_points * n_frames;
+    }
 #undef HFPF_LAUNCH_INTEGRATE
     HIPCHK(h, hipGetLastError());
     if (h->timing) {
@@ -759,7 +819,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         int per_cu = 0, cus = 0;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate<true, false>, 256, 0) != hipSuccess) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate<true, false, false>, 256, 0) != hipSuccess) per_cu = 4;
         h->integrate_grid = std::max(1, per_cu) * std::max(1, cus);
     }
     if ((rc = alloc_tables(h))) return bail(rc);
@@ -777,7 +837,7 @@ int hfpf_destroy(hfpf_handle* h)
     for (DevBuf* b : {&h->sort_tmp, &h->keys_a, &h->keys_b, &h->vals_a, &h->vals_b, &h->rows_dev, &h->probe_a, &h->probe_b, &h->probe_c, &h->probe_d,
                       &h->probe_e, &h->probe_f})
         if (b->p) (void)hipFree(b->p);
-    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->cstats_total})
+    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->cstats_total, &h->bin_pt_buf, &h->bin_rgb_buf})
         if (b->p) (void)hipFree(b->p);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t_)h->comm);
     if (h->h_counts) (void)hipHostFree(h->h_counts);

@@ -87,7 +87,7 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool PACKED16, bool COLOR>
+template <bool PACKED16, bool COLOR, bool BIN>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
@@ -188,8 +188,49 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         c_buf += buf;
 
         // dependant updates (grid.hpp:244-277)
-        const uint32_t cnt = act ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u;
+        uint32_t cnt = act ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u;
         const uint64_t off = info >> kDepOffShift;
+        if (BIN) {
+            // Two-pass form: park the point in its brick's bin; k_update accumulates every brick's records in LDS and
+            // flushes each record once per launch instead of once per (point, dependant) pair.  One reservation per
+            // distinct brick per wave (ballot grouping); a lane whose brick region is full (or unplanned) keeps cnt and
+            // takes the direct path below, so correctness never depends on the plan.
+            const bool want_bin = cnt > 0;
+            // phase 1 (registers only): group the lanes by brick -> leader lane, rank in group, group size
+            uint32_t grp_leader = lane, grp_rank = 0, grp_size = 0;
+            unsigned long long m = __ballot(want_bin);
+            while (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t lb = __shfl(b, leader);
+                const bool same = want_bin && b == lb;
+                const unsigned long long sm = __ballot(same);
+                if (same) {
+                    grp_leader = (uint32_t)leader;
+                    grp_rank = (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                    grp_size = (uint32_t)__popcll(sm);
+                }
+                m &= ~sm;
+            }
+            // phase 2: every group leader reserves for its group in ONE wave-instruction (one memory round trip per tile)
+            uint32_t base = 0, cap = 0, roff = 0;
+            if (want_bin && grp_leader == lane) {
+                base = atomicAdd(&t.bin_fill[b], grp_size);
+                cap = t.bin_capb[b];
+                roff = t.bin_off[b];
+            }
+            base = __shfl(base, (int)grp_leader);
+            cap = __shfl(cap, (int)grp_leader);
+            roff = __shfl(roff, (int)grp_leader);
+            if (want_bin) {
+                const uint32_t pos = base + grp_rank;
+                if (pos < cap) {
+                    const uint64_t e = (uint64_t)roff + pos;
+                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
+                    if (COLOR) t.bin_rgb[e] = rgb;
+                    cnt = 0;  // handled by k_update
+                }
+            }
+        }
         uint32_t max_cnt = cnt;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, o));
@@ -230,6 +271,125 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
     }
     __syncthreads();
     if (threadIdx.x < 6 && blk_ctr[threadIdx.x]) atomicAdd(&t.ctr[C_PRESENTED + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K2 (binned form): one workgroup per brick.  The brick's parked points are read back coalesced; every
+// (point, dependant) member pair adds its 7-word delta to an LDS table keyed by record id (open addressing,
+// LDS atomics), and the table is flushed with the same 8-lanes-per-record cooperative atomics, so a record costs
+// one memory-side request per brick per launch.  A full table falls back to direct device atomics.
+constexpr int kUpdSlots = 512;
+__device__ __forceinline__ uint32_t upd_hash(uint32_t sid) { return (sid * 2654435761u) >> 23; }  // 9 bits
+
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables t, const uint32_t n_bricks)
+{
+    __shared__ uint32_t keys[kUpdSlots];
+    __shared__ unsigned long long vals[kUpdSlots * SW_USED];
+    __shared__ unsigned long long cvals[COLOR ? kUpdSlots * 3 : 1];
+    __shared__ unsigned int blk_ctr[2];
+    const uint32_t b = blockIdx.x + 1;
+    if (b > n_bricks) return;
+    const uint32_t fill = min(t.bin_fill[b], t.bin_capb[b]);
+    if (fill == 0) return;  // block-uniform
+    for (uint32_t i = threadIdx.x; i < kUpdSlots; i += 256) keys[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kUpdSlots * SW_USED; i += 256) vals[i] = 0;
+    if (COLOR)
+        for (uint32_t i = threadIdx.x; i < kUpdSlots * 3; i += 256) cvals[i] = 0;
+    if (threadIdx.x < 2) blk_ctr[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t first = t.bin_off[b];
+    uint32_t c_tested = 0, c_member = 0;
+    for (uint32_t i = threadIdx.x; i < fill; i += 256) {
+        const float4 pe = t.bin_pt[first + i];
+        const uint32_t rgb = COLOR ? t.bin_rgb[first + i] : 0u;
+        const F3 p = F3{pe.x, pe.y, pe.z};
+        const uint64_t info = t.info[__float_as_uint(pe.w)];
+        const uint32_t cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+        const uint64_t off = info >> kDepOffShift;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const DepEntry e = t.dep[off + j];
+            F3 proj;
+            double dist;
+            c_tested++;
+            if (!cylinder_member(g, p, F3{e.cx, e.cy, e.cz}, F3{e.nx, e.ny, e.nz}, proj, dist)) continue;
+            c_member++;
+            StatDeltaT<COLOR> d;
+            stat_delta_zero(d);
+            stat_delta_add(d, g, proj, F3{e.cx, e.cy, e.cz}, dist, rgb);
+            uint32_t h = upd_hash(e.sid);
+            bool placed = false;
+            for (int probe = 0; probe < 16; probe++) {
+                const uint32_t old = atomicCAS(&keys[h], 0u, e.sid);
+                if (old == 0u || old == e.sid) {
+                    placed = true;
+                    break;
+                }
+                h = (h + 1) & (kUpdSlots - 1);
+            }
+            if (placed) {
+#pragma unroll
+                for (int w = 0; w < SW_USED; w++) atomicAdd(&vals[h * SW_USED + w], (unsigned long long)d.v[w]);
+                if constexpr (COLOR) {
+                    atomicAdd(&cvals[h * 3 + 0], (unsigned long long)d.rgb[0]);
+                    atomicAdd(&cvals[h * 3 + 1], (unsigned long long)d.rgb[1]);
+                    atomicAdd(&cvals[h * 3 + 2], (unsigned long long)d.rgb[2]);
+                }
+            } else {  // table full: straight to HBM
+#pragma unroll
+                for (int w = 0; w < SW_USED; w++) atomicAdd(&t.stats[(uint64_t)e.sid * kStatWords + w], (unsigned long long)d.v[w]);
+                if constexpr (COLOR) {
+                    atomicAdd(&t.cstats[(uint64_t)e.sid * 4 + 0], (unsigned long long)d.rgb[0]);
+                    atomicAdd(&t.cstats[(uint64_t)e.sid * 4 + 1], (unsigned long long)d.rgb[1]);
+                    atomicAdd(&t.cstats[(uint64_t)e.sid * 4 + 2], (unsigned long long)d.rgb[2]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {  // flush: 8 lanes per record, 32 records per pass
+        const uint32_t w = threadIdx.x & 7u;
+        for (uint32_t sl = threadIdx.x >> 3; sl < kUpdSlots; sl += 32) {
+            const uint32_t key = keys[sl];
+            if (key != 0u && w < SW_USED) atomicAdd(&t.stats[(uint64_t)key * kStatWords + w], vals[sl * SW_USED + w]);
+            if (COLOR && key != 0u && w < 3) atomicAdd(&t.cstats[(uint64_t)key * 4 + w], cvals[sl * 3 + w]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_tested += __shfl_down(c_tested, o);
+        c_member += __shfl_down(c_member, o);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (c_tested) atomicAdd(&blk_ctr[0], c_tested);
+        if (c_member) atomicAdd(&blk_ctr[1], c_member);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_ctr[0]) atomicAdd(&t.ctr[C_DEP_TESTED], (unsigned long long)blk_ctr[0]);
+    if (threadIdx.x == 1 && blk_ctr[1]) atomicAdd(&t.ctr[C_DEP_MEMBER], (unsigned long long)blk_ctr[1]);
+}
+
+// Plan the brick regions of the next launch from the demand of the previous one: cap = demand * scale * 1.25 + 64.
+__global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_bricks, const float scale)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_bricks) return;
+    uint32_t cap = 0;
+    if (b >= 1) {
+        const uint32_t demand = t.bin_fill[b];
+        if (demand) cap = (uint32_t)((float)demand * scale * 1.25f) + 64u;
+    }
+    t.bin_capb[b] = cap;
+}
+
+// After the exclusive scan of the capacities: regions that do not fit the pool are switched off.
+__global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_t n_bricks, const uint64_t pool)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_bricks) return;
+    if ((uint64_t)t.bin_off[b] + t.bin_capb[b] > pool) t.bin_capb[b] = 0;
+    t.bin_fill[b] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

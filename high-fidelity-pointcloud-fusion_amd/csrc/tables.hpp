@@ -116,6 +116,12 @@ struct Tables {
     uint64_t* cand_key;    // clean scratch (unsorted / sorted ping-pong handled by the host)
     float* frame_vp;       // 3 per frame id
     unsigned long long* ctr;
+    // brick bins of the two-pass dependant update (kernels.hpp, k_integrate<BIN> + k_update)
+    float4* bin_pt;       // (x, y, z, slot bits) of points parked for k_update, grouped per brick
+    uint32_t* bin_rgb;    // their colour (HFPF_FLAG_FUSE_COLOR only)
+    uint32_t* bin_fill;   // per brick: entries requested in the running launch (may exceed the region)
+    uint32_t* bin_off;    // per brick: first entry of its region
+    uint32_t* bin_capb;   // per brick: entries its region can hold (0 = not planned: direct atomics)
     unsigned long long* log_ctr;  // kLogRegions append counters, one per 128-byte line (index r*16)
     uint64_t log_region_cap;      // entries per log region
     uint64_t max_bricks, max_log, max_occ, max_normals, max_reg, max_dep, max_frames;

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("HFPF_LIB") or os.path.join(CSRC_DIR, "libhfpf.so")  #
 
 FLAG_FUSE_COLOR = 1
 FLAG_PCL_SHIFTED_COV = 2
+FLAG_DIRECT_UPDATE = 4
 STATUS = {0: "OK", -1: "BAD_CONFIG", -2: "BAD_ARG", -3: "CAPACITY", -4: "HIP", -5: "STATE", -6: "IO", -7: "DIST"}
 
 
@@ -177,7 +178,7 @@ class OccupancyGrid:
     """Device-resident occupancy grid.  Keyword defaults are the reference's constants."""
 
     def __init__(self, resolution=None, bbox=None, k=None, K=None, gate=None, cylinder_radius=None, ball_radius=None,
-                 z_clip=None, device=0, max_bricks=0, max_log_points=0, max_normals=0, max_frames=0, fuse_color=False, pcl_shifted_cov=False):
+                 z_clip=None, device=0, max_bricks=0, max_log_points=0, max_normals=0, max_frames=0, fuse_color=False, pcl_shifted_cov=False, binned_update=None):
         L = lib()
         c = default_config()
         if resolution is not None:
@@ -194,7 +195,10 @@ class OccupancyGrid:
         if z_clip is not None:
             c.z_clip_min, c.z_clip_max = z_clip
         c.device = device
-        c.flags = (FLAG_FUSE_COLOR if fuse_color else 0) | (FLAG_PCL_SHIFTED_COV if pcl_shifted_cov else 0)
+        if binned_update is None:
+            binned_update = os.environ.get("HFPF_BINNED", "1") != "0"  # HFPF_BINNED=0: A/B against the direct form
+        c.flags = ((FLAG_FUSE_COLOR if fuse_color else 0) | (FLAG_PCL_SHIFTED_COV if pcl_shifted_cov else 0) |
+                   (0 if binned_update else FLAG_DIRECT_UPDATE))
         c.max_bricks, c.max_log_points, c.max_normals, c.max_frames = max_bricks, max_log_points, max_normals, max_frames
         self.cfg = c
         self._transport = None

@@ -26,6 +26,10 @@ extern "C" {
 
 /* hfpf_config.flags */
 #define HFPF_FLAG_FUSE_COLOR 1u /* EXTENSION: also average the member points' RGB per voxel (reference: never, grid.hpp:471-479) */
+#define HFPF_FLAG_DIRECT_UPDATE 4u /* dependant updates with one memory-side atomic per (point, dependant) pair.  Default (flag
+                                      clear) is the two-pass form: points are binned per 8x8x8 brick, one workgroup per brick
+                                      accumulates its statistic records in LDS and flushes each once per launch.  Same results
+                                      either way (the sums are integers); the binned form is ~1.5x faster on the bench. */
 #define HFPF_FLAG_PCL_SHIFTED_COV 2u /* plane fit with pcl::computeMeanAndCovarianceMatrix as PCL >= 1.11 computes it (moments of
                                         p - first point).  Default (0) is the single-pass form of PCL <= 1.10; the two differ
                                         visibly in f32 ~1 m from the origin (call site grid.hpp:302) */

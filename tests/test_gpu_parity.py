@@ -129,3 +129,20 @@ def test_batched_device_frames_equal_single_host_frames(hfpf_mod, synth_mod):
         rb = b.extract()
         b.device_free(dev)
     assert ra.tobytes() == rb.tobytes()
+
+
+@pytest.mark.parametrize("binned", [True, False])
+def test_binned_and_direct_update_are_bit_identical(oracle_mod, hfpf_mod, synth_mod, binned):
+    """The two forms of the dependant update (LDS-staged brick bins vs one atomic per pair) give the same bits."""
+    sc = scenes.Scene(7, 160, 120, 0.001, fx=615.0, clean_every=2)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ref = scenes.run(og, sc, "capture")
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, binned_update=binned, **SMALL) as g:
+        got = scenes.run(g, sc, "integrate")
+        ctr = g.counters()
+    scenes.compare_rows(ref, got)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, binned_update=not binned, **SMALL) as g2:
+        other = scenes.run(g2, sc, "integrate")
+        ctr2 = g2.counters()
+    assert got.tobytes() == other.tobytes()
+    assert ctr["dep_pairs_tested"] == ctr2["dep_pairs_tested"] and ctr["dep_pairs_member"] == ctr2["dep_pairs_member"]
