@@ -441,6 +441,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     const bool color = h->t.cstats != nullptr;
     const bool bin = h->binned;
     const uint32_t nb = (uint32_t)h->n_bricks_known;
+    const bool demand_only = h->h_ctr[C_NORMALS] == 0;  // as of the last clean: nothing can have dependants yet
     if (bin) {
         // pool for this launch's parked points (+25 % plan slack, +64 per brick)
         const uint64_t pts = (uint64_t)n_points * n_frames;
@@ -453,8 +454,9 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
             h->bin_pool = pool;
         }
         h->t.bin_pt = (float4*)h->bin_pt_buf.p;
+        h->t.bin_demand_only = demand_only ? 1u : 0u;
         h->t.bin_rgb = (uint32_t*)h->bin_rgb_buf.p;
-        if (h->bin_have_hist && nb > 0) {
+        if (h->bin_have_hist && nb > 0 && !demand_only) {
             const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points));
             hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, h->stream, h->t, nb, scale);
             size_t bytes = 0;
@@ -481,7 +483,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, true);
         else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, true);
         else HFPF_LAUNCH_INTEGRATE(false, true, true);
-        if (nb > 0 && h->bin_have_hist) {
+        if (nb > 0 && h->bin_have_hist && !demand_only) {
             if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
             else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
         }

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             // flushes each record once per launch instead of once per (point, dependant) pair.  One reservation per
             // distinct brick per wave (ballot grouping); a lane whose brick region is full (or unplanned) keeps cnt and
             // takes the direct path below, so correctness never depends on the plan.
-            const bool want_bin = cnt > 0;
+            const bool want_bin = cnt > 0 || (act && t.bin_demand_only);
             // phase 1 (registers only): group the lanes by brick -> leader lane, rank in group, group size
             uint32_t grp_leader = lane, grp_rank = 0, grp_size = 0;
             unsigned long long m = __ballot(want_bin);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             base = __shfl(base, (int)grp_leader);
             cap = __shfl(cap, (int)grp_leader);
             roff = __shfl(roff, (int)grp_leader);
-            if (want_bin) {
+            if (want_bin && cnt > 0) {
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
                     const uint64_t e = (uint64_t)roff + pos;

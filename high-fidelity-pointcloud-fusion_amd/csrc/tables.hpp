@@ -122,6 +122,8 @@ struct Tables {
     uint32_t* bin_fill;   // per brick: entries requested in the running launch (may exceed the region)
     uint32_t* bin_off;    // per brick: first entry of its region
     uint32_t* bin_capb;   // per brick: entries its region can hold (0 = not planned: direct atomics)
+    uint32_t bin_demand_only;  // 1 while no voxel has a normal yet: count every in-bbox point per brick so the first
+                               // launch with dependants already has a plan; nothing is parked
     unsigned long long* log_ctr;  // kLogRegions append counters, one per 128-byte line (index r*16)
     uint64_t log_region_cap;      // entries per log region
     uint64_t max_bricks, max_log, max_occ, max_normals, max_reg, max_dep, max_frames;
