@@ -292,6 +292,7 @@ int alloc_tables(hfpf_handle* h)
     t.max_occ = c.max_normals * 4;
     t.max_reg = c.max_normals * (2ull * (uint64_t)c.K + 1ull);
     t.max_dep = 2 * t.max_reg;  // room for the lists the incremental update relocates
+    if (t.max_dep > 0xFFFFFFF0ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_normals too large: the dependant table must stay below 2^32 entries");
     t.max_frames = c.max_frames;
     h->n_slots = (t.max_bricks + 1) * (uint64_t)kBrickCells;
     h->max_touched = t.max_reg;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
                     const uint64_t e = (uint64_t)roff + pos;
-                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
+                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)off));  // the point + where its dependant list starts
                     if (COLOR) t.bin_rgb[e] = rgb;
                     cnt = 0;  // handled by k_update
                 }
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
         const float4 pe = t.bin_pt[first + i];
         const uint32_t rgb = COLOR ? t.bin_rgb[first + i] : 0u;
         const F3 p = F3{pe.x, pe.y, pe.z};
-        const uint64_t info = t.info[__float_as_uint(pe.w)];
-        const uint32_t cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-        const uint64_t off = info >> kDepOffShift;
+        const uint64_t off = __float_as_uint(pe.w);  // start of the point's dependant list (< 2^32, checked at create)
+        uint32_t cnt = 1;
         for (uint32_t j = 0; j < cnt; j++) {
             const DepEntry e = t.dep[off + j];
+            if (j == 0) cnt = e.pad;  // the first entry of a list carries its length
             F3 proj;
             double dist;
             c_tested++;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_dep_fill(const Tables t, const uint64_t
     e.nx = t.nv_n[3 * (uint64_t)nid];
     e.ny = t.nv_n[3 * (uint64_t)nid + 1];
     e.nz = t.nv_n[3 * (uint64_t)nid + 2];
-    e.pad = 0;
+    e.pad = k == 0 ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u;  // the first entry carries the list length
     t.dep[(info >> kDepOffShift) + k] = e;
 }
 
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_
 // fresh space at the end of dep[] and the new entries appended.  The space of the old list is garbage
 // until the next full rebuild (k_dep_count / k_dep_offsets / k_dep_fill), which the host runs when dep[]
 // fills up.
-__device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid)
+__device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid, uint32_t list_len_if_first = 0)
 {
     DepEntry e;
     e.sid = nid;
@@ -718,7 +718,7 @@ __device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid
     e.nx = t.nv_n[3 * (uint64_t)nid];
     e.ny = t.nv_n[3 * (uint64_t)nid + 1];
     e.nz = t.nv_n[3 * (uint64_t)nid + 2];
-    e.pad = 0;
+    e.pad = list_len_if_first;  // entry 0 of a list: its length (read by k_update); otherwise unused
     return e;
 }
 
@@ -756,7 +756,11 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
         t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
         return;
     }
-    for (uint32_t k = 0; k < old_cnt; k++) t.dep[new_off + k] = t.dep[old_off + k];
+    for (uint32_t k = 0; k < old_cnt; k++) {
+        DepEntry e = t.dep[old_off + k];
+        if (k == 0) e.pad = new_cnt;  // the first entry carries the list length
+        t.dep[new_off + k] = e;
+    }
     t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)new_off << kDepOffShift);
     t.dep_tmp[slot] = old_cnt;  // append cursor
 }
@@ -768,7 +772,8 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
     const uint2 r = t.reg_occ[j];
     const uint32_t k = atomicAdd(&t.dep_tmp[r.x], 1u);
     if (k & 0x80000000u) return;
-    t.dep[(t.info[r.x] >> kDepOffShift) + k] = make_dep_entry(t, r.y);
+    const uint64_t info = t.info[r.x];
+    t.dep[(info >> kDepOffShift) + k] = make_dep_entry(t, r.y, k == 0 ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u);
 }
 
 // Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
         }
         t.info[slot] = (info & 3ull) | (1ull << kDepCntShift) | (off << kDepOffShift);
     }
-    t.dep[off] = make_dep_entry(t, t.pre_dep[slot]);
+    t.dep[off] = make_dep_entry(t, t.pre_dep[slot], 1u);
 }
 
 // ---- K6 extract -----------------------------------------------------------------------------------
