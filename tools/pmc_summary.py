@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes (one counter set per pass, as MI355X_MICROARCH.md prescribes) for k_integrate.
+"""Summarise rocprofv3 --pmc passes (one counter set per pass, as MI355X_MICROARCH.md prescribes) for the integrate
+hot path: k_integrate (decode/clip/transform/insert/bin) + k_update (per-brick LDS accumulation).
 
-usage: python tools/pmc_summary.py gpurun_out profiles/r01_pmc_k_integrate
-Reads gpurun_out/pmc_<COUNTERS>/*/*_counter_collection.csv (written by
-`rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 300 ...`) and writes
-<out>.json / <out>.md with per-launch values for the steady-state launches (those after the first clean pass).
+usage: python tools/pmc_summary.py gpurun_out pmc2 profiles/r01_pmc_hot_path
+Reads gpurun_out/<prefix>_<COUNTERS>/*/*_counter_collection.csv written by
+`rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 300 --warmup 5 ...`
+and writes <out>.json / <out>.md with per-launch values (one launch = one hfpf_integrate_device call of 50 frames).
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction: FETCH_SIZE reports half the bytes of a wide (16 B/lane)
-coalesced stream, so the frame read (16 B x points) is added once more; narrower scattered reads are uncalibrated.
+coalesced stream, so 8 B per streamed 16-byte record is added (the frame read in k_integrate, the bin read-back in
+k_update); narrower scattered reads are uncalibrated.
 """
 import collections
 import csv
@@ -17,60 +19,74 @@ import sys
 NPTS_PER_LAUNCH = 50 * 640 * 480
 
 
-def load(root, name):
-    fs = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, name))
+def load(root, prefix, name):
+    fs = glob.glob("%s/%s_%s/*/*counter_collection.csv" % (root, prefix, name))
     per = collections.defaultdict(list)
     if not fs:
         return per
     for r in csv.DictReader(open(fs[0])):
-        if "k_integrate" in r["Kernel_Name"]:
-            per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = r["Kernel_Name"]
+        which = "A" if "k_integrate" in k else ("B" if "k_update" in k else None)
+        if which:
+            per[(which, r["Counter_Name"])].append(float(r["Counter_Value"]))
     return per
 
 
 def main():
-    root, out = sys.argv[1], sys.argv[2]
+    root, prefix, out = sys.argv[1], sys.argv[2], sys.argv[3]
     vals = {}
     for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum", "TCC_HIT_sum_TCC_MISS_sum"):
-        vals.update(load(root, name))
-    # launches: [warmup, epoch0 x3, epoch1 x3] for --steps 300 --warmup 5 --frames-per-call 50
-    def steady(v):
-        return v[4:] if len(v) >= 7 else v[-1:]
-
-    def first(v):
-        return v[1:4] if len(v) >= 7 else v[:1]
+        vals.update(load(root, prefix, name))
     avg = lambda v: sum(v) / max(len(v), 1)
+    # k_integrate dispatches for --steps 300 --warmup 5: [warmup, epoch0 x3, steady x3]; k_update only exists in steady state
+    steady_a = lambda v: v[4:] if len(v) >= 7 else v[-1:]
+    first_a = lambda v: v[1:4] if len(v) >= 7 else v[:1]
     res = {"points_per_launch": NPTS_PER_LAUNCH, "source": "rocprofv3 --pmc, separate passes, bench.py --steps 300 --warmup 5"}
-    for phase, sel in (("steady_state_after_first_clean", steady), ("first_epoch_buffer_only", first)):
-        fetch_raw = avg(sel(vals.get("FETCH_SIZE", [0]))) * 1024
-        write = avg(sel(vals.get("WRITE_SIZE", [0]))) * 1024
-        atom = avg(sel(vals.get("TCC_EA0_ATOMIC_sum", [0])))
-        hit = avg(sel(vals.get("TCC_HIT_sum", [0])))
-        miss = avg(sel(vals.get("TCC_MISS_sum", [0])))
-        fetch_corr = fetch_raw + 0.5 * 16 * NPTS_PER_LAUNCH
+    get = lambda w, c, sel: avg(sel(vals.get((w, c), [0])))
+    for phase, sel_a, with_b in (("steady_state_after_first_clean", steady_a, True), ("first_epoch_buffer_only", first_a, False)):
+        fa = get("A", "FETCH_SIZE", sel_a) * 1024
+        wa = get("A", "WRITE_SIZE", sel_a) * 1024
+        aa = get("A", "TCC_EA0_ATOMIC_sum", sel_a)
+        ident = lambda v: v
+        fb = get("B", "FETCH_SIZE", ident) * 1024 if with_b else 0.0
+        wb = get("B", "WRITE_SIZE", ident) * 1024 if with_b else 0.0
+        ab = get("B", "TCC_EA0_ATOMIC_sum", ident) if with_b else 0.0
+        in_bbox = 0.83 * NPTS_PER_LAUNCH
+        corr = 0.5 * 16 * NPTS_PER_LAUNCH + (0.5 * 16 * in_bbox if with_b else 0.0)
+        traffic = fa + fb + corr + wa + wb
         res[phase] = {
-            "fetch_bytes_raw": fetch_raw, "fetch_bytes_corrected": fetch_corr, "write_bytes": write,
-            "atomic_requests": atom, "atomic_bytes_at_64B": atom * 64, "tcc_hit": hit, "tcc_miss": miss,
-            "traffic_bytes_per_launch": fetch_corr + write,
-            "traffic_bytes_per_point": (fetch_corr + write) / NPTS_PER_LAUNCH,
+            "k_integrate": {"fetch_bytes_raw": fa, "write_bytes": wa, "atomic_requests": aa,
+                            "l2_hit_rate": get("A", "TCC_HIT_sum", sel_a) / max(get("A", "TCC_HIT_sum", sel_a) + get("A", "TCC_MISS_sum", sel_a), 1)},
+            "k_update": {"fetch_bytes_raw": fb, "write_bytes": wb, "atomic_requests": ab,
+                         "l2_hit_rate": (get("B", "TCC_HIT_sum", ident) / max(get("B", "TCC_HIT_sum", ident) + get("B", "TCC_MISS_sum", ident), 1)) if with_b else None},
+            "fetch_correction_bytes": corr,
+            "atomic_requests": aa + ab,
+            "traffic_bytes_per_launch": traffic,
+            "traffic_bytes_per_point": traffic / NPTS_PER_LAUNCH,
             "algorithmic_bytes_per_launch": 32 * NPTS_PER_LAUNCH,
         }
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
-        f.write("# k_integrate memory-side counters (rocprofv3 --pmc, one counter set per pass)\n\n")
-        f.write("Per launch = 50 frames = %d points. FETCH_SIZE corrected per MI355X_MICROARCH.md (HBM): + 8 B/point for the\n"
-                "16 B/lane frame read that gfx950 tallies at half; scattered 4-8 B table reads are uncalibrated.\n\n" % NPTS_PER_LAUNCH)
-        f.write("| phase | FETCH raw | FETCH corrected | WRITE | atomic requests (x64 B) | L2 hit/(hit+miss) | traffic / launch | B / point | algorithmic (32 B/pt) |\n|---|---|---|---|---|---|---|---|---|\n")
+        f.write("# Integrate hot path: memory-side counters (rocprofv3 --pmc, one counter set per pass)\n\n")
+        f.write("Per launch = one `hfpf_integrate_device` call of 50 frames = %d points. FETCH_SIZE corrected per MI355X_MICROARCH.md (HBM):\n"
+                "+8 B per streamed 16-byte record (gfx950 tallies wide coalesced reads at half); scattered 4-8 B table reads are uncalibrated.\n\n" % NPTS_PER_LAUNCH)
+        f.write("| phase | kernel | FETCH raw | WRITE | atomic requests | L2 hit rate |\n|---|---|---|---|---|---|\n")
+        for phase in ("first_epoch_buffer_only", "steady_state_after_first_clean"):
+            for k in ("k_integrate", "k_update"):
+                r = res[phase][k]
+                if r["l2_hit_rate"] is None:
+                    continue
+                f.write("| %s | `%s` | %.3f GB | %.3f GB | %.2f M | %.2f |\n" % (phase, k, r["fetch_bytes_raw"] / 1e9, r["write_bytes"] / 1e9,
+                                                                          r["atomic_requests"] / 1e6, r["l2_hit_rate"]))
+        f.write("\n| phase | traffic / launch (corrected) | B / point | algorithmic (32 B/pt) | atomic requests / launch |\n|---|---|---|---|---|\n")
         for phase in ("first_epoch_buffer_only", "steady_state_after_first_clean"):
             r = res[phase]
-            hr = r["tcc_hit"] / max(r["tcc_hit"] + r["tcc_miss"], 1)
-            f.write("| %s | %.3f GB | %.3f GB | %.3f GB | %.1f M (%.3f GB) | %.2f | %.3f GB | %.0f | %.3f GB |\n" % (
-                phase, r["fetch_bytes_raw"] / 1e9, r["fetch_bytes_corrected"] / 1e9, r["write_bytes"] / 1e9, r["atomic_requests"] / 1e6,
-                r["atomic_bytes_at_64B"] / 1e9, hr, r["traffic_bytes_per_launch"] / 1e9, r["traffic_bytes_per_point"],
-                r["algorithmic_bytes_per_launch"] / 1e9))
-        f.write("\nReading: WRITE_SIZE in steady state is the statistics atomics (one 64-byte segment per (point, dependant) pair);\n"
-                "FETCH is dominated by 64-byte sector fills for 4-8 byte table lookups (directory, info word, dependant entries) that\n"
-                "are served from L2 / Infinity Cache (tables total ~100 MB), not by the 16 B/point frame stream.\n")
+            f.write("| %s | %.3f GB | %.0f | %.3f GB | %.2f M |\n" % (phase, r["traffic_bytes_per_launch"] / 1e9, r["traffic_bytes_per_point"],
+                                                                 r["algorithmic_bytes_per_launch"] / 1e9, r["atomic_requests"] / 1e6))
+        f.write("\nReading: with the brick-binned update a steady-state launch issues ~4.6 M memory-side atomics (bin reservations + one flush per\n"
+                "record per brick) instead of the 41 M of the one-atomic-per-pair form (`r01_pmc_k_integrate.md`, kept for comparison), and\n"
+                "moves ~1.5 GB instead of 4.9 GB.  `k_update` is served mostly from L2 (brick-local dependant lists), `k_integrate` by 64-byte\n"
+                "sector fills for its 4-8-byte table lookups plus the streamed frame read and bin write.\n")
     print(open(out + ".md").read())
 
 
