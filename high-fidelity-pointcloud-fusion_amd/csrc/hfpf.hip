@@ -82,6 +82,9 @@ struct hfpf_handle {
     int integrate_grid = 1536;
     uint64_t frames_integrated = 0;
     uint64_t reg_done = 0;  // reg_occ entries already present in dep[]
+    uint64_t gate_done = 0; // occ_list entries already examined by a gate pass
+    uint64_t n_pend = 0;    // cells examined before that still have no normal (pend_a)
+    DevBuf pend_a, pend_b;
     uint64_t clean_passes = 0;
     uint32_t next_frame_id = 0;
 
@@ -251,7 +254,7 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.dir, 0, h->dir_entries * 4, s));
     HIPCHK(h, hipMemsetAsync(t.info, 0, h->n_slots * 8, s));
     HIPCHK(h, hipMemsetAsync(t.first_frame, 0xFF, h->n_slots * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.buf_head, 0, h->n_slots * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.buf_head, 0, h->n_slots * 4 * kChains, s));
     HIPCHK(h, hipMemsetAsync(t.stat_id, 0, h->n_slots * 4, s));
     HIPCHK(h, hipMemsetAsync(t.pre_dep, 0, h->n_slots * 4, s));
     HIPCHK(h, hipMemsetAsync(t.dep_tmp, 0, h->n_slots * 4, s));
@@ -268,6 +271,8 @@ int reset_state(hfpf_handle* h)
     h->dirty = false;
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
     h->reg_done = 0;
+    h->gate_done = 0;
+    h->n_pend = 0;
     h->occ_exported = 0;
     h->next_frame_id = 0;
     return HFPF_OK;
@@ -303,7 +308,7 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(brick_lin, t.max_bricks + 1);
     ALLOC(info, h->n_slots, 0, false);
     ALLOC(first_frame, h->n_slots, 0, false);
-    ALLOC(buf_head, h->n_slots, 0, false);
+    ALLOC(buf_head, h->n_slots * kChains, 0, false);
     ALLOC(stat_id, h->n_slots, 0, false);
     ALLOC(pre_dep, h->n_slots, 0, false);
     ALLOC(dep_tmp, h->n_slots, 0, false);
@@ -676,12 +681,23 @@ int clean_locked(hfpf_handle* h)
     }
     if (n_occ == 0) return HFPF_OK;
 
+    // candidates: the cells that failed the gate last time (pending list) + the cells occupied since (new tail of occ_list)
+    const uint64_t n_new_occ = n_occ - std::min(n_occ, h->gate_done);
+    if ((rc = scratch(h, h->pend_b, std::max<uint64_t>(h->n_pend + n_new_occ, 1) * 4))) return rc;
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_PEND, 0ull);
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_PRECHG, 0ull);
-    hipLaunchKernelGGL(k_gate, dim3(blocks_for(n_occ, 256)), dim3(256), 0, s, h->g, t, n_occ);
+    if (h->n_pend)
+        hipLaunchKernelGGL(k_gate, dim3(blocks_for(h->n_pend, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->pend_a.p, h->n_pend, (uint32_t*)h->pend_b.p);
+    if (n_new_occ)
+        hipLaunchKernelGGL(k_gate, dim3(blocks_for(n_new_occ, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ,
+                           (uint32_t*)h->pend_b.p);
     HIPCHK(h, hipGetLastError());
+    h->gate_done = n_occ;
     if ((rc = read_counters(h))) return rc;
     const uint64_t n_cand = h->h_ctr[C_CAND];
+    std::swap(h->pend_a, h->pend_b);  // cells that got a normal in this pass are dropped by the next gate's kNormal test
+    h->n_pend = h->h_ctr[C_PEND];
     if (n_cand == 0) return HFPF_OK;
     if (n_normals + n_cand > t.max_normals)
         return fail(h, HFPF_ERR_CAPACITY, "normal records: %llu + %llu > max_normals %llu", (unsigned long long)n_normals,
@@ -752,9 +768,9 @@ int clean_locked(hfpf_handle* h)
         if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
         if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched))) return rc;
         if (t.cstats)
-            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
         else
-            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
         HIPCHK(h, hipGetLastError());
     }
     h->reg_done = n_reg;
@@ -840,7 +856,7 @@ int hfpf_destroy(hfpf_handle* h)
     for (DevBuf* b : {&h->sort_tmp, &h->keys_a, &h->keys_b, &h->vals_a, &h->vals_b, &h->rows_dev, &h->probe_a, &h->probe_b, &h->probe_c, &h->probe_d,
                       &h->probe_e, &h->probe_f})
         if (b->p) (void)hipFree(b->p);
-    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->cstats_total, &h->bin_pt_buf, &h->bin_rgb_buf})
+    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->cstats_total, &h->bin_pt_buf, &h->bin_rgb_buf, &h->pend_a, &h->pend_b})
         if (b->p) (void)hipFree(b->p);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t_)h->comm);
     if (h->h_counts) (void)hipHostFree(h->h_counts);

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_
 // ------------------------------------------------------------------------------------------------
 // Link the log entries appended since the last clean into their cells' chains.  grid.y = log region;
 // [first[r], last[r]] are 1-based global entry indices (empty when first > last).
+constexpr uint32_t kChains = 4;  // interleaved chains per cell: k_replay walks them with 4 lanes in parallel
 struct LinkRanges {
     uint32_t first[kLogRegions];
     uint32_t last[kLogRegions];
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void k_link_log(const Tables t, const LinkRang
     if (e > lr.last[r]) return;
     uint32_t* w = reinterpret_cast<uint32_t*>(&t.log_pt[e]) + 3;
     const uint32_t slot = *w;
-    *w = atomicExch(&t.buf_head[slot], (uint32_t)e);
+    *w = atomicExch(&t.buf_head[(uint64_t)slot * kChains + (e & (kChains - 1))], (uint32_t)e);  // entry e joins chain e mod 4 of its cell
 }
 
 // 125-bit occupancy stencil around (x,y,z): bit d = ((dx+2)*5 + (dy+2))*5 + (dz+2), the setK table order
@@ -442,13 +443,15 @@ __device__ inline void neighbourhood(const GridParams& g, const Tables& t, int32
 
 // K3: every occupied cell without a normal is a candidate (the reference's unprocessed_data_ set is
 // a superset whose extra members fail the same gate, grid.hpp:315,352).
-__global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t, const uint64_t n_occ)
+__global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint64_t n_cells,
+                                              uint32_t* __restrict__ pend_out)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pass = false;
+    bool pass = false, pend = false;
     uint64_t key = 0;
-    if (j < n_occ) {
-        const uint32_t slot = t.occ_list[j];
+    uint32_t slot = 0;
+    if (j < n_cells) {
+        slot = cells[j];
         if (!(t.info[slot] & kNormal)) {
             int32_t x, y, z;
             slot_coords(g, t, slot, x, y, z);
@@ -456,12 +459,15 @@ __global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t
             neighbourhood(g, t, x, y, z, lo, hi);
             const int total = __popcll(lo) + __popcll(hi);
             pass = total > g.gate;
+            pend = !pass;  // still without a normal: look at it again next pass (its neighbourhood may fill up)
             key = make_key(x, y, z);
         }
     }
     __shared__ BlockReserveScratch brs;
     const unsigned long long ci = block_reserve(&t.ctr[C_CAND], pass, brs);
-    if (pass) t.cand_key[ci] = key;  // capacity = max_occ >= n_occ
+    if (pass) t.cand_key[ci] = key;  // capacity = max_occ >= cells examined
+    const unsigned long long pi = block_reserve(&t.ctr[C_PEND], pend, brs);
+    if (pend) pend_out[pi] = slot;
 }
 
 // K4: one thread per candidate, in ascending key order; record id = base + rank + 1.
@@ -476,16 +482,31 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
     const uint32_t slot = slot_lookup(g, t, x, y, z);
     uint64_t lo, hi;
     neighbourhood(g, t, x, y, z, lo, hi);
+    // the cell centre is separable: 5 values per axis (grid.hpp:131-135 evaluated once each) instead of 125 x 3
+    float cxs[5], cys[5], czs[5];
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+        const F3 c = voxel_center(g, x + a - 2, y + a - 2, z + a - 2);
+        cxs[a] = c.x;
+        cys[a] = c.y;
+        czs[a] = c.z;
+    }
     Moments m;
     m.clear();
     int total = 0;
-    for (int d = 0; d < 125; d++) {
-        const bool set = d < 64 ? ((lo >> d) & 1ull) : ((hi >> (d - 64)) & 1ull);
-        if (!set) continue;
-        const int a = d / 25 - 2, bq = (d / 5) % 5 - 2, c = d % 5 - 2;
-        m.add(voxel_center(g, x + a, y + bq, z + c), g.cov_shifted != 0);  // grid.hpp:364-369
-        total++;
-    }
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int bq = 0; bq < 5; bq++) {
+            const int d0 = (a * 5 + bq) * 5;
+            const uint32_t bits5 = (uint32_t)((d0 < 64 ? (lo >> d0) | (d0 + 5 > 64 ? hi << (64 - d0) : 0ull) : hi >> (d0 - 64)) & 31ull);
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                if ((bits5 >> c) & 1u) {
+                    m.add(F3{cxs[a], cys[bq], czs[c]}, g.cov_shifted != 0);  // grid.hpp:364-369, setK order (x outer, z inner)
+                    total++;
+                }
+        }
     F3 normal = m.normal(total);
     const F3 centre = voxel_center(g, x, y, z);  // grid.hpp:391
     const uint32_t ff = t.first_frame[slot];
@@ -570,7 +591,9 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
 {
     __shared__ unsigned long long queue[4][64 * kQueueStride];
     unsigned long long* q = queue[threadIdx.x >> 6];
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = gid / kChains;           // cell
+    const uint32_t sub = (uint32_t)(gid % kChains);  // which of the cell's interleaved chains this lane walks
     uint32_t slot = 0, cnt = 0, head = 0;
     uint64_t off = 0;
     if (j < n_touched) {
@@ -579,8 +602,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         if (info & kOcc) {  // only occupied cells have a buffer
             cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
             off = info >> kDepOffShift;
-            head = t.buf_head[slot];
-            if (head == 0) cnt = 0;
+            head = t.buf_head[(uint64_t)slot * kChains + sub];
         }
     }
     uint32_t replayed = 0;
@@ -633,7 +655,24 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         }
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const bool member = d[k].v[SW_COUNT] != 0;
+            // sum the four sub-chains of the cell (lanes 4i..4i+3) before the flush: one record update per (cell, registrant)
+#pragma unroll
+            for (int w = 0; w < SW_USED; w++) {
+                long long v = d[k].v[w];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                d[k].v[w] = v;
+            }
+            if constexpr (COLOR) {
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    long long v = d[k].rgb[w];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    d[k].rgb[w] = v;
+                }
+            }
+            const bool member = sub == 0 && d[k].v[SW_COUNT] != 0;
             if (member) replayed += (uint32_t)d[k].v[SW_COUNT];
             wave_flush_members(t, q, member, d[k], sid[k]);
         }

@@ -10,7 +10,7 @@
 //   per slot:  info u64              bit0 occupied (Voxel::occupied), bit1 normal_found,
 //                                    bits 2..17 dependant count, bits 18..63 offset into dep[]
 //              first_frame u32       smallest frame id that touched the cell (-> VoxelInfo::viewpoint, grid.hpp:229,238)
-//              buf_head u32          head of the cell's chain in the point log (VoxelInfo::buffer)
+//              buf_head u32[4]       heads of the cell's 4 interleaved chains in the point log (VoxelInfo::buffer)
 //              stat_id u32           1-based id of the cell's normal/statistics record, 0 = none
 //              pre_dep u32           the one dependant registered while the cell was unoccupied
 //                                    (grid.hpp:443-449 overwrite semantics: last registrant wins)
@@ -63,6 +63,7 @@ enum Ctr : int {
     C_DEP_MEMBER,
     C_ROWS,         // rows valid at extract
     C_REPLAY_MEMBER, // buffered points that fell inside a cylinder during clean-time replay
+    C_PEND,         // occupied cells still without a normal after the running gate pass
     C_PRECHG,       // unoccupied cells whose single dependant changed in the running clean pass
     C_COUNT = 32
 };
