@@ -268,6 +268,7 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.bin_capb, 0, (t.max_bricks + 2) * 4, s));
     h->bin_have_hist = false;
     h->n_bricks_known = 0;
+    if (h->h_ctr) memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));  // host mirror follows the device counters
     h->dirty = false;
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
     h->reg_done = 0;
