@@ -279,8 +279,11 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 // (point, dependant) member pair adds its 7-word delta to an LDS table keyed by record id (open addressing,
 // LDS atomics), and the table is flushed with the same 8-lanes-per-record cooperative atomics, so a record costs
 // one memory-side request per brick per launch.  A full table falls back to direct device atomics.
-constexpr int kUpdSlots = 512;
-__device__ __forceinline__ uint32_t upd_hash(uint32_t sid) { return (sid * 2654435761u) >> 23; }  // 9 bits
+#ifndef HFPF_UPD_BITS
+#define HFPF_UPD_BITS 9  // log2 of the LDS table size of k_update
+#endif
+constexpr int kUpdSlots = 1 << HFPF_UPD_BITS;
+__device__ __forceinline__ uint32_t upd_hash(uint32_t sid) { return (sid * 2654435761u) >> (32 - HFPF_UPD_BITS); }
 
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables t, const uint32_t n_bricks)
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
     __syncthreads();
     {  // flush: 8 lanes per record, 32 records per pass
         const uint32_t w = threadIdx.x & 7u;
-        for (uint32_t sl = threadIdx.x >> 3; sl < kUpdSlots; sl += 32) {
+        for (uint32_t sl = threadIdx.x >> 3; sl < (uint32_t)kUpdSlots; sl += 32) {
             const uint32_t key = keys[sl];
             if (key != 0u && w < SW_USED) atomicAdd(&t.stats[(uint64_t)key * kStatWords + w], vals[sl * SW_USED + w]);
             if (COLOR && key != 0u && w < 3) atomicAdd(&t.cstats[(uint64_t)key * 4 + w], cvals[sl * 3 + w]);
