@@ -1,13 +1,18 @@
 // csrc/kernels.hpp -- HIP kernels of the fusion path (gfx950, 64-wide waves).
 //
-//   K1 k_integrate        decode + z-clip + SE(3) + bbox clip + voxel index + insert/append + dependant updates
-//                         (node.cpp:190-214,251-255,289; grid.hpp:194-277)
+//   K1 k_integrate        decode + z-clip + SE(3) + bbox clip + voxel index + brick claim + insert/append; points whose cell
+//                         has dependants are parked in their brick's bin (node.cpp:190-214,251-255,289; grid.hpp:194-243)
+//   K2 k_update           dependant updates per brick: LDS-staged statistic records, one flush per record (grid.hpp:244-277)
+//      (k_integrate<.., BIN=false> keeps the direct form: one memory-side atomic per (point, dependant) pair)
+//      k_bin_plan/clamp   per-brick bin regions of the next launch from the previous launch's demand
 //   K3 k_gate             5x5x5 occupancy count and the >gate test            (grid.hpp:322-352)
 //   K4 k_normal           plane fit on occupied neighbour centres, orientation (grid.hpp:356-398)
 //   K5 k_register         +-K line walk, dependant registration (grid.hpp:403-417,443-449)
+//      k_link_log         chains the point-log entries appended since the last clean (4 interleaved chains per cell)
 //      k_replay           buffer replay of the cells that gained registrants (grid.hpp:418-440)
-//      k_dep_*            rebuild of the per-cell dependant table
+//      k_depinc_*/k_dep_* incremental update / compacting rebuild of the per-cell dependant table
 //   K6 k_extract_*        ordered compaction of normal_found voxels            (grid.hpp:463-480)
+//      k_epoch_*          multi-GPU exchange of newly occupied cells
 #pragma once
 #include "stats.hpp"
 
@@ -26,12 +31,12 @@ struct FrameLayout {
 // issuer (MI355X_MICROARCH.md "fanin"), so diagnostics stay in registers until the block retires and the
 // point log is striped over kLogRegions append regions with one counter per 128-byte line.
 //
-// Dependant updates: every (point, dependant) pair that falls inside the 1 mm cylinder adds 7 int64
-// words to ONE 64-byte statistics record.  A lane-per-pair loop would issue 7 fully scattered atomic
-// instructions per round (64 lanes x 7 = 448 memory-side requests); instead the member lanes park their
-// deltas in a per-wave LDS queue and the wave replays the queue with 8 lanes per record, so one
-// wave-instruction carries 8 whole records, each as 8-byte lanes of one contiguous 64-byte segment
-// (64 requests per round at most, measured 1.8x faster than two segments per record).
+// Dependant updates, direct form (BIN = false, and the fallback of the binned form): every (point, dependant) pair
+// inside the 1 mm cylinder adds 7 int64 words to ONE 64-byte statistics record.  A lane-per-pair loop would issue 7
+// fully scattered atomic instructions per round (448 memory-side requests); instead the member lanes park their deltas
+// in a per-wave LDS queue and the wave replays the queue with 8 lanes per record, so one wave-instruction carries 8 whole
+// records as one 64-byte segment each.  That form saturates the chip's ~20 G requests/s atomic unit (41 M per launch).
+// Binned form (BIN = true, default): the point is parked in its brick's bin and k_update does the pairs brick by brick.
 #ifndef HFPF_REPLAY_B
 #define HFPF_REPLAY_B 3  // registrants per chain walk held in registers by k_replay
 #endif
