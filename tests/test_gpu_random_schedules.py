@@ -1,0 +1,72 @@
+"""GPU: randomised explicit schedules.  Every schedule is a legal interleaving of the reference node: random
+runs of frames, cleans at random points (also twice in a row, or with nothing new), extracts mid-stream (the reference's
+process does not stop capture), clears, and both forms of the dependant update.  Engine and oracle get the same script."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(max_bricks=60000, max_log_points=4 << 20, max_normals=1 << 20, max_frames=4096)
+
+
+def _script(rng, n_frames):
+    ops, f = [], 0
+    while f < n_frames:
+        r = rng.random()
+        if r < 0.55:
+            run = int(rng.integers(1, 4))
+            for _ in range(min(run, n_frames - f)):
+                ops.append(("integrate", f))
+                f += 1
+        elif r < 0.80:
+            ops.append(("clean",))
+            if rng.random() < 0.2:
+                ops.append(("clean",))  # a second pass with nothing new is a no-op for the rows
+        elif r < 0.92:
+            ops.append(("extract",))
+        else:
+            ops.append(("clear",))
+    ops += [("clean",), ("extract",)]
+    return ops
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_schedule(oracle_mod, hfpf_mod, synth_mod, seed):
+    rng = np.random.default_rng(1000 + seed)
+    res, fx, W, H = [(0.001, 615.0, 128, 96), (0.005, 0.0, 128, 96), (0.002, 615.0, 160, 120)][seed % 3]
+    cfg = {}
+    if rng.random() < 0.3:
+        cfg["K"] = int(rng.integers(1, 5))
+    if rng.random() < 0.3:
+        cfg["gate"] = int(rng.integers(12, 30))
+    if rng.random() < 0.2:
+        cfg["pcl_shifted_cov"] = True
+    sc = scenes.Scene(int(rng.integers(5, 10)), W, H, res, fx=fx, seed=0xF051 + seed, pose_seed=0x5E3 + seed)
+    ops = _script(rng, sc.n_frames)
+    og = oracle_mod.OracleGrid(resolution=res, bbox=sc.bbox, **cfg)
+    eg = hfpf_mod.OccupancyGrid(resolution=res, bbox=sc.bbox, binned_update=bool(seed % 2), **cfg, **SMALL)
+    n_checked = 0
+    try:
+        for op in ops:
+            if op[0] == "integrate":
+                buf = sc.frame(op[1])
+                og.capture(buf, sc.poses[op[1]])
+                eg.integrate(buf, sc.poses[op[1]])
+            elif op[0] == "clean":
+                og.clean()
+                eg.clean()
+                assert eg.state_changed == og.is_dirty()
+            elif op[0] == "extract":
+                ref, got = og.extract(), eg.extract()
+                scenes.compare_rows(ref, got)
+                n_checked += 1
+            else:
+                og.clear()
+                eg.clear()
+                assert len(eg.extract()) == 0
+        assert np.array_equal(og.occupied(), eg.occupied())
+    finally:
+        eg.close()
+        og.close()
+    assert n_checked >= 1
