@@ -40,6 +40,9 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <omp.h>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -584,8 +587,269 @@ public:
         }
     }
 
+
+    // ---- all-cores variant (TIMING BASELINE ONLY; never used for parity) -----------------------------------------
+    // The reference's engine is serial (its OpenMP pragmas are commented out, grid.hpp:190-193,318-321).  This is the
+    // "fair multi-core comparison" of BASELINE.md: the same per-point work spread over OpenMP threads with the voxel
+    // store sharded 256 ways (one mutex per shard).  Welford updates happen in arrival order, so floats differ in the
+    // last bits from run to run; counts, occupancy and normals do not.  Clean stays sequential except the plane fits.
+    static constexpr int kShards = 256;
+    struct Shard {
+        std::mutex m;
+        std::unordered_map<uint64_t, Voxel> map;
+    };
+    std::unique_ptr<Shard[]> shards_;
+    static int shard_of(uint64_t key) { return (int)((key * 0x9E3779B97F4A7C15ull) >> 56); }
+
+    void capture_mt(const uint8_t* base, size_t n, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                    const double* T)
+    {
+        if (!shards_) shards_.reset(new Shard[kShards]);
+        state_changed = true;
+        const V3 viewpoint = {(float)T[3], (float)T[7], (float)T[11]};
+        uint64_t presented = 0, zpass = 0, inserted = 0;
+#pragma omp parallel for schedule(static) reduction(+ : presented, zpass, inserted)
+        for (long long i = 0; i < (long long)n; i++) {
+            const uint8_t* rec = base + (size_t)i * point_step;
+            float x, y, z;
+            memcpy(&x, rec + off_x, 4);
+            memcpy(&y, rec + off_y, 4);
+            memcpy(&z, rec + off_z, 4);
+            presented++;
+            if (!((double)z < cfg.z_clip_max && (double)z > cfg.z_clip_min)) continue;
+            zpass++;
+            V3 q;
+            q.x = (float)(T[0] * (double)x + T[1] * (double)y + T[2] * (double)z + T[3]);
+            q.y = (float)(T[4] * (double)x + T[5] * (double)y + T[6] * (double)z + T[7]);
+            q.z = (float)(T[8] * (double)x + T[9] * (double)y + T[10] * (double)z + T[11]);
+            int vx, vy, vz;
+            voxel_coords(q, vx, vy, vz);
+            if (!valid_point(q) || vx == INT_MIN || vy == INT_MIN || vz == INT_MIN) continue;
+            inserted++;
+            const uint64_t key = own_key(vx, vy, vz);
+            uint64_t deps_inline[24];
+            std::vector<uint64_t> deps_spill;
+            const uint64_t* deps = deps_inline;
+            size_t n_deps = 0;
+            {
+                Shard& sh = shards_[shard_of(key)];
+                std::lock_guard<std::mutex> lk(sh.m);
+                Voxel& voxel = sh.map[key];
+                if (!voxel.data) voxel.data = new VoxelInfo();
+                if (voxel.occupied) {
+                    if (!voxel.data->normal_found) voxel.data->buffer.push_back(q);
+                } else {
+                    voxel.occupied = true;
+                    voxel.data->viewpoint = viewpoint;
+                    voxel.data->buffer.push_back(q);
+                }
+                // copied so that no two shard locks are ever held together
+                const std::vector<uint64_t>& dv = voxel.data->dependants;
+                n_deps = dv.size();
+                if (n_deps <= 24) {
+                    for (size_t d = 0; d < n_deps; d++) deps_inline[d] = dv[d];
+                } else {
+                    deps_spill = dv;
+                    deps = deps_spill.data();
+                }
+            }
+            for (size_t d = 0; d < n_deps; d++) {
+                const uint64_t dk = deps[d];
+                int xx, yy, zz;
+                own_coords(dk, xx, yy, zz);
+                const V3 centre = voxel_center(xx, yy, zz);
+                Shard& ds = shards_[shard_of(dk)];
+                std::lock_guard<std::mutex> lk(ds.m);
+                VoxelInfo* dep = ds.map.find(dk)->second.data;
+                V3 proj = project_point_to_vector(q, centre, dep->normal, ball_r_f);
+                double distance_to_normal = (double)norm3(sub3(q, proj));
+                if (distance_to_normal < cfg.cylinder_radius) welford(dep, proj, distance_to_normal);
+            }
+        }
+        n_presented += presented;
+        n_zclip_pass += zpass;
+        n_inserted += inserted;
+    }
+
+    Voxel lookup_mt(int x, int y, int z) const
+    {
+        const uint64_t k = own_key(x, y, z);
+        const Shard& sh = shards_[shard_of(k)];
+        auto it = sh.map.find(k);
+        if (it == sh.map.end()) return Voxel();
+        return it->second;
+    }
+
+    void clean_mt()
+    {
+        state_changed = false;
+        if (!shards_) return;
+        const bool trace = getenv("HORACLE_TRACE") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = now();
+        std::vector<uint64_t> keys;  // sorted for locality only: the one order-dependent rule is resolved by key below
+        {
+            std::vector<std::vector<uint64_t>> part(kShards);
+#pragma omp parallel for schedule(dynamic, 4)
+            for (int s = 0; s < kShards; s++)
+                for (auto& kv : shards_[s].map)
+                    if (kv.second.occupied && !kv.second.data->normal_found) part[s].push_back(kv.first);
+            for (int s = 0; s < kShards; s++) keys.insert(keys.end(), part[s].begin(), part[s].end());
+            std::sort(keys.begin(), keys.end());
+        }
+        const int nd = (int)dx.size();
+        double t1 = now();
+        std::vector<V3> normals(keys.size());
+        std::vector<uint8_t> gated(keys.size(), 0);
+#pragma omp parallel for schedule(dynamic, 256)
+        for (long long ki = 0; ki < (long long)keys.size(); ki++) {  // occupancy is frozen during a pass: fits are independent
+            int x, y, z;
+            own_coords(keys[ki], x, y, z);
+            std::vector<V3> cloud;
+            for (int d = 0; d < nd; d++) {
+                const int xx = x + dx[d], yy = y + dy[d], zz = z + dz[d];
+                if (valid_coord(xx, yy, zz) && lookup_mt(xx, yy, zz).occupied) cloud.push_back(voxel_center(xx, yy, zz));
+            }
+            if ((int)cloud.size() > cfg.gate) {
+                V3 nrm{0, 0, 0};
+                get_normal(cloud.data(), (int)cloud.size(), nrm, cfg.pcl_shifted_cov != 0);
+                const V3 centroid = voxel_center(x, y, z);
+                const V3 vp = lookup_mt(x, y, z).data->viewpoint;
+                const V3 dir = normalized3(sub3(vp, centroid));
+                if (dot3(dir, nrm) < 0.0f) nrm = {nrm.x * -1.0f, nrm.y * -1.0f, nrm.z * -1.0f};
+                normals[ki] = nrm;
+                gated[ki] = 1;
+            }
+        }
+        double t2 = now();
+        // Registration + replay, parallel over candidates.  A candidate only writes its own statistics, point buffers are
+        // frozen during a pass, appends to an occupied target's dependant list take the target's shard lock, and the
+        // "last registrant in canonical order wins" overwrite of unoccupied targets (grid.hpp:443-449) is resolved
+        // afterwards from a sorted list.
+        struct Pre {
+            uint64_t target, owner;
+        };
+        std::vector<Pre> pre_all;
+#pragma omp parallel
+        {
+            std::vector<Pre> pre;
+#pragma omp for schedule(dynamic, 64) nowait
+            for (long long ki = 0; ki < (long long)keys.size(); ki++) {
+                if (!gated[ki]) continue;
+                int x, y, z;
+                own_coords(keys[ki], x, y, z);
+                VoxelInfo* data;
+                {
+                    Shard& sh = shards_[shard_of(keys[ki])];
+                    std::lock_guard<std::mutex> lk(sh.m);
+                    data = sh.map.find(keys[ki])->second.data;
+                }
+                data->normal = normals[ki];
+                data->normal_found = true;
+                const V3 centroid = voxel_center(x, y, z);
+                for (int i = -cfg.K; i <= cfg.K; i++) {
+                    const float step = (float)((double)i * xres_);
+                    V3 nb = add3(centroid, mul3(step, data->normal));
+                    if (!valid_point(nb)) continue;
+                    int xx, yy, zz;
+                    voxel_coords(nb, xx, yy, zz);
+                    if (xx == INT_MIN || yy == INT_MIN || zz == INT_MIN || !valid_coord(xx, yy, zz)) continue;
+                    const uint64_t nk = own_key(xx, yy, zz);
+                    VoxelInfo* target = nullptr;
+                    {
+                        Shard& sh = shards_[shard_of(nk)];
+                        std::lock_guard<std::mutex> lk(sh.m);
+                        auto it = sh.map.find(nk);
+                        if (it != sh.map.end() && it->second.occupied) {
+                            target = it->second.data;
+                            target->dependants.push_back(keys[ki]);
+                        }
+                    }
+                    if (!target) {
+                        pre.push_back({nk, keys[ki]});
+                        continue;
+                    }
+                    const size_t bl = target->buffer.size();
+                    for (size_t b = 0; b < bl; b++) {
+                        const V3 pt = target->buffer[b];
+                        V3 proj = project_point_to_vector(pt, centroid, data->normal, ball_r_f);
+                        double distance_to_normal = (double)norm3(sub3(pt, proj));
+                        if (distance_to_normal < cfg.cylinder_radius) welford(data, proj, distance_to_normal);
+                    }
+                }
+            }
+#pragma omp critical
+            pre_all.insert(pre_all.end(), pre.begin(), pre.end());
+        }
+        double t3 = now();
+        {
+            std::vector<std::vector<Pre>> bucket(kShards);
+            for (const Pre& pr : pre_all) bucket[shard_of(pr.target)].push_back(pr);
+#pragma omp parallel for schedule(dynamic, 4)
+            for (int sh = 0; sh < kShards; sh++) {
+                std::vector<Pre>& b = bucket[sh];
+                std::sort(b.begin(), b.end(),
+                          [](const Pre& a, const Pre& c) { return a.target != c.target ? a.target < c.target : a.owner < c.owner; });
+                for (size_t i = 0; i < b.size(); i++) {
+                    if (i + 1 < b.size() && b[i + 1].target == b[i].target) continue;  // a later registrant overwrites
+                    Voxel& nv = shards_[sh].map[b[i].target];
+                    delete nv.data;
+                    nv.data = new VoxelInfo();
+                    nv.data->dependants.push_back(b[i].owner);
+                }
+            }
+        }
+        if (trace)
+            fprintf(stderr, "clean_mt: %zu keys gather %.3f fit %.3f register+replay %.3f overwrite %.3f s\n", keys.size(), t1 - t0,
+                    t2 - t1, t3 - t2, now() - t3);
+    }
+
+    void extract_mt(std::vector<Row>& rows) const
+    {
+        rows.clear();
+        if (!shards_) return;
+        std::vector<std::pair<uint64_t, const VoxelInfo*>> found;
+        for (int s = 0; s < kShards; s++)
+            for (auto& kv : shards_[s].map) {
+                if (!kv.second.occupied || !kv.second.data->normal_found) continue;
+                int x, y, z;
+                own_coords(kv.first, x, y, z);
+                if (valid_coord(x, y, z)) found.push_back({kv.first, kv.second.data});
+            }
+        std::sort(found.begin(), found.end());
+        rows.resize(found.size());
+        for (size_t i = 0; i < found.size(); i++) {
+            const VoxelInfo* d = found[i].second;
+            Row& r = rows[i];
+            own_coords(found[i].first, r.ix, r.iy, r.iz);
+            r.count = (uint32_t)d->count;
+            r.x = d->centroid.x, r.y = d->centroid.y, r.z = d->centroid.z;
+            r.nx = d->normal.x, r.ny = d->normal.y, r.nz = d->normal.z;
+            r.sdx = d->sd.x, r.sdy = d->sd.y, r.sdz = d->sd.z;
+            r.mean_dist = d->mean_dist;
+            r.sd_dist = d->sd_dist;
+            r.rgb = 0;
+        }
+    }
+
+    uint64_t count_normals_mt() const
+    {
+        uint64_t n = 0;
+        if (shards_)
+            for (int s = 0; s < kShards; s++)
+                for (auto& kv : shards_[s].map)
+                    if (kv.second.occupied && kv.second.data->normal_found) n++;
+        return n;
+    }
+
     void clear()
     {
+        if (shards_) {
+            for (int sh = 0; sh < kShards; sh++) {
+                for (auto& kv : shards_[sh].map) delete kv.second.data;
+                shards_[sh].map.clear();
+            }
+        }
         for (auto& kv : voxels_) delete kv.second.data;
         voxels_.clear();
         unprocessed_.clear();
@@ -619,12 +883,36 @@ void horacle_add_points(void* h, const float* xyz, uint64_t n, const float* vp)
     ((Oracle*)h)->add_points((const V3*)xyz, n, V3{vp[0], vp[1], vp[2]});
 }
 void horacle_clean(void* h) { ((Oracle*)h)->clean(); }
+// all-cores timing baseline (separate voxel store; do not mix with the sequential calls on one handle)
+void horacle_capture_mt(void* h, const void* base, uint64_t n, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                        const double* pose)
+{
+    ((Oracle*)h)->capture_mt((const uint8_t*)base, n, point_step, off_x, off_y, off_z, pose);
+}
+void horacle_clean_mt(void* h) { ((Oracle*)h)->clean_mt(); }
+// thread count of the all-cores variant; returns what OpenMP will use
+int32_t horacle_set_threads(int32_t n)
+{
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
+uint64_t horacle_normals_mt(void* h) { return ((Oracle*)h)->count_normals_mt(); }
 int32_t horacle_is_dirty(void* h) { return ((Oracle*)h)->state_changed ? 1 : 0; }
 void horacle_clear(void* h) { ((Oracle*)h)->clear(); }
 uint64_t horacle_extract(void* h, Row* out, uint64_t cap)
 {
     std::vector<Row> rows;
     ((Oracle*)h)->extract(rows);
+    if (out) {
+        uint64_t n = std::min<uint64_t>(cap, rows.size());
+        memcpy(out, rows.data(), n * sizeof(Row));
+    }
+    return rows.size();
+}
+uint64_t horacle_extract_mt(void* h, Row* out, uint64_t cap)
+{
+    std::vector<Row> rows;
+    ((Oracle*)h)->extract_mt(rows);
     if (out) {
         uint64_t n = std::min<uint64_t>(cap, rows.size());
         memcpy(out, rows.data(), n * sizeof(Row));

@@ -64,6 +64,14 @@ def lib():
                                       C.c_uint32, C.c_void_p]
         L.horacle_add_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.horacle_clean.argtypes = [C.c_void_p]
+        L.horacle_capture_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.horacle_clean_mt.argtypes = [C.c_void_p]
+        L.horacle_normals_mt.argtypes = [C.c_void_p]
+        L.horacle_normals_mt.restype = C.c_uint64
+        L.horacle_set_threads.argtypes = [C.c_int32]
+        L.horacle_set_threads.restype = C.c_int32
+        L.horacle_extract_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.horacle_extract_mt.restype = C.c_uint64
         L.horacle_is_dirty.argtypes = [C.c_void_p]
         L.horacle_is_dirty.restype = C.c_int32
         L.horacle_clear.argtypes = [C.c_void_p]
@@ -110,6 +118,11 @@ def make_config(resolution=0.005, bbox=(-0.8, 1.8, -1.5, 1.5, 0.0, 1.0), k=2, K=
     return c
 
 
+def set_threads(n):
+    """Thread count used by capture_mt/clean_mt (0 = leave as is); returns the count in effect."""
+    return int(lib().horacle_set_threads(int(n)))
+
+
 class OracleGrid:
     """Explicit-schedule driver of the restated OccupancyGrid + capture stage."""
 
@@ -142,6 +155,28 @@ class OracleGrid:
         if n_points is None:
             n_points = buf.nbytes // point_step
         lib().horacle_capture(self._h, _p(buf), n_points, point_step, off_x, off_y, off_z, _p(pose))
+
+    # All-cores timing baseline: own sharded voxel store, float results not run-to-run reproducible.  Never mix with
+    # capture()/clean() on one grid and never use it as a parity checker.
+    def capture_mt(self, buf, pose, n_points=None, point_step=16, off_x=0, off_y=4, off_z=8):
+        buf = np.ascontiguousarray(buf)
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        if n_points is None:
+            n_points = buf.nbytes // point_step
+        lib().horacle_capture_mt(self._h, _p(buf), n_points, point_step, off_x, off_y, off_z, _p(pose))
+
+    def clean_mt(self):
+        lib().horacle_clean_mt(self._h)
+
+    def normals_mt(self):
+        return int(lib().horacle_normals_mt(self._h))
+
+    def extract_mt(self):
+        n = lib().horacle_extract_mt(self._h, None, 0)
+        rows = np.zeros(n, dtype=ROW_DTYPE)
+        if n:
+            lib().horacle_extract_mt(self._h, _p(rows), n)
+        return rows
 
     def add_points(self, xyz, viewpoint=(0, 0, 0)):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

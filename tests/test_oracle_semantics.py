@@ -183,3 +183,24 @@ def test_libstdcpp_order_mode_changes_only_rounding_and_overwrites(oracle_mod, s
     assert differ <= 0.02 * len(ra)
     same = ra["count"] == rb["count"]
     assert np.allclose(ra["x"][same], rb["x"][same], atol=1e-5)
+
+
+def test_all_cores_timing_variant_computes_the_same_map(oracle_mod, synth_mod):
+    """capture_mt/clean_mt is bench.py's all-cores CPU baseline, not a checker.  It still has to do the same work:
+    the emitted voxel set, every points-in-cylinder count and every normal are order-independent and must be
+    identical to the serial oracle; the float Welford fields may differ in the last bits (arrival order)."""
+    sc = scenes.Scene(6, 160, 120, 0.005, clean_every=2)
+    ga = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ra = scenes.run(ga, sc, "capture")
+    gb = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    for ev in sc.schedule():
+        if ev[0] == "integrate":
+            gb.capture_mt(sc.frame(ev[1]), sc.poses[ev[1]])
+        else:
+            gb.clean_mt()
+    rb = gb.extract_mt()
+    assert gb.normals_mt() == len(rb)
+    assert len(ra) > 1000
+    scenes.compare_rows(ra, rb)
+    gb.clear()
+    assert gb.normals_mt() == 0
