@@ -41,7 +41,9 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#ifdef _OPENMP
 #include <omp.h>
+#endif
 #include <chrono>
 #include <string>
 #include <unordered_map>
@@ -893,8 +895,13 @@ void horacle_clean_mt(void* h) { ((Oracle*)h)->clean_mt(); }
 // thread count of the all-cores variant; returns what OpenMP will use
 int32_t horacle_set_threads(int32_t n)
 {
+#ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);
     return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;  // built without -fopenmp: the pragmas are ignored and the variant runs on one thread
+#endif
 }
 uint64_t horacle_normals_mt(void* h) { return ((Oracle*)h)->count_normals_mt(); }
 int32_t horacle_is_dirty(void* h) { return ((Oracle*)h)->state_changed ? 1 : 0; }
