@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--clean-every", type=int, default=150)
-    ap.add_argument("--frames-per-call", type=int, default=50)
+    ap.add_argument("--frames-per-call", type=int, default=150, help="frames handed to one hfpf_integrate_device call (one clean epoch by default)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--write-dir", default=None, help="also time writing test_cloud.pcd (ASCII + binary) and meta.csv there")
     ap.add_argument("--host-path-frames", type=int, default=20, help="frames also pushed through the host-buffer entry point")
@@ -166,7 +166,7 @@ def main():
 
     def run_stream(n_frames, timed):
         done = 0
-        B = max(1, min(args.frames_per_call, (50 * 307200) // NPTS))
+        B = max(1, min(args.frames_per_call, int(os.environ.get("HFPF_BENCH_CALL_POINTS", 150 * 307200)) // NPTS))
         while done < n_frames:
             nxt = n_frames
             if args.clean_every:
