@@ -2,10 +2,11 @@
 """Summarise rocprofv3 --pmc passes (one counter set per pass, as MI355X_MICROARCH.md prescribes) for the integrate
 hot path: k_integrate (decode/clip/transform/insert/bin) + k_update (per-brick LDS accumulation).
 
-usage: python tools/pmc_summary.py gpurun_out pmc2 profiles/r01_pmc_hot_path
+usage: python tools/pmc_summary.py gpurun_out pmc3 profiles/r01_pmc_hot_path [frames_per_launch=150]
 Reads gpurun_out/<prefix>_<COUNTERS>/*/*_counter_collection.csv written by
-`rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 300 --warmup 5 ...`
-and writes <out>.json / <out>.md with per-launch values (one launch = one hfpf_integrate_device call of 50 frames).
+`rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 600 --warmup 5 ...`
+and writes <out>.json / <out>.md with per-launch values (one launch = one hfpf_integrate_device call of 150 frames,
+bench.py's default: one clean epoch per call).
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction: FETCH_SIZE reports half the bytes of a wide (16 B/lane)
 coalesced stream, so 8 B per streamed 16-byte record is added (the frame read in k_integrate, the bin read-back in
 k_update); narrower scattered reads are uncalibrated.
@@ -16,11 +17,12 @@ import glob
 import json
 import sys
 
-NPTS_PER_LAUNCH = 50 * 640 * 480
+FRAMES_PER_LAUNCH = 150
+NPTS_PER_LAUNCH = FRAMES_PER_LAUNCH * 640 * 480
 
 
 def load(root, prefix, name):
-    fs = glob.glob("%s/%s_%s/*/*counter_collection.csv" % (root, prefix, name))
+    fs = glob.glob("%s/%s_%s/*/*counter_collection.csv" % (root, prefix, name)) + glob.glob("%s/%s_%s/*counter_collection.csv" % (root, prefix, name))
     per = collections.defaultdict(list)
     if not fs:
         return per
@@ -33,15 +35,22 @@ def load(root, prefix, name):
 
 
 def main():
+    global FRAMES_PER_LAUNCH, NPTS_PER_LAUNCH
     root, prefix, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    if len(sys.argv) > 4:
+        FRAMES_PER_LAUNCH = int(sys.argv[4])
+        NPTS_PER_LAUNCH = FRAMES_PER_LAUNCH * 640 * 480
     vals = {}
     for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum", "TCC_HIT_sum_TCC_MISS_sum"):
         vals.update(load(root, prefix, name))
     avg = lambda v: sum(v) / max(len(v), 1)
-    # k_integrate dispatches for --steps 300 --warmup 5: [warmup, epoch0 x3, steady x3]; k_update only exists in steady state
-    steady_a = lambda v: v[4:] if len(v) >= 7 else v[-1:]
-    first_a = lambda v: v[1:4] if len(v) >= 7 else v[:1]
-    res = {"points_per_launch": NPTS_PER_LAUNCH, "source": "rocprofv3 --pmc, separate passes, bench.py --steps 300 --warmup 5"}
+    # k_integrate dispatches for --steps 600 --warmup 5 --clean-every 150: [warm-up, first epoch x n_first, steady x rest];
+    # k_update only exists in steady state
+    n_first = max(1, 150 // FRAMES_PER_LAUNCH)
+    steady_a = lambda v: v[1 + n_first:] if len(v) > 1 + n_first else v[-1:]
+    first_a = lambda v: v[1:1 + n_first] if len(v) > 1 + n_first else v[:1]
+    res = {"points_per_launch": NPTS_PER_LAUNCH, "frames_per_launch": FRAMES_PER_LAUNCH,
+           "source": "rocprofv3 --pmc, separate passes, bench.py --steps 600 --warmup 5"}
     get = lambda w, c, sel: avg(sel(vals.get((w, c), [0])))
     for phase, sel_a, with_b in (("steady_state_after_first_clean", steady_a, True), ("first_epoch_buffer_only", first_a, False)):
         fa = get("A", "FETCH_SIZE", sel_a) * 1024
@@ -68,8 +77,8 @@ def main():
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
         f.write("# Integrate hot path: memory-side counters (rocprofv3 --pmc, one counter set per pass)\n\n")
-        f.write("Per launch = one `hfpf_integrate_device` call of 50 frames = %d points. FETCH_SIZE corrected per MI355X_MICROARCH.md (HBM):\n"
-                "+8 B per streamed 16-byte record (gfx950 tallies wide coalesced reads at half); scattered 4-8 B table reads are uncalibrated.\n\n" % NPTS_PER_LAUNCH)
+        f.write("Per launch = one `hfpf_integrate_device` call of %d frames = %d points. FETCH_SIZE corrected per MI355X_MICROARCH.md (HBM):\n"
+                "+8 B per streamed 16-byte record (gfx950 tallies wide coalesced reads at half); scattered 4-8 B table reads are uncalibrated.\n\n" % (FRAMES_PER_LAUNCH, NPTS_PER_LAUNCH))
         f.write("| phase | kernel | FETCH raw | WRITE | atomic requests | L2 hit rate |\n|---|---|---|---|---|---|\n")
         for phase in ("first_epoch_buffer_only", "steady_state_after_first_clean"):
             for k in ("k_integrate", "k_update"):
@@ -83,10 +92,12 @@ def main():
             r = res[phase]
             f.write("| %s | %.3f GB | %.0f | %.3f GB | %.2f M |\n" % (phase, r["traffic_bytes_per_launch"] / 1e9, r["traffic_bytes_per_point"],
                                                                  r["algorithmic_bytes_per_launch"] / 1e9, r["atomic_requests"] / 1e6))
-        f.write("\nReading: with the brick-binned update a steady-state launch issues ~4.6 M memory-side atomics (bin reservations + one flush per\n"
-                "record per brick) instead of the 41 M of the one-atomic-per-pair form (`r01_pmc_k_integrate.md`, kept for comparison), and\n"
-                "moves ~1.5 GB instead of 4.9 GB.  `k_update` is served mostly from L2 (brick-local dependant lists), `k_integrate` by 64-byte\n"
-                "sector fills for its 4-8-byte table lookups plus the streamed frame read and bin write.\n")
+        st = res["steady_state_after_first_clean"]
+        f.write("\nReading: with the brick-binned update a steady-state launch issues %.1f M memory-side atomics (bin reservations + one flush per\n"
+                "record per brick) instead of one per (point, dependant) pair (`r01_pmc_k_integrate.md`, the earlier form, kept for comparison:\n"
+                "41 M atomics and 4.9 GB per 50 frames), and moves %.0f B per point.  `k_update` is served mostly from L2 (brick-local dependant\n"
+                "lists), `k_integrate` by sector fills for its 4-8-byte table lookups plus the streamed frame read and bin write.\n"
+                % (st["atomic_requests"] / 1e6, st["traffic_bytes_per_point"]))
     print(open(out + ".md").read())
 
 
