@@ -126,7 +126,8 @@ def main():
             device = local_rank % n_dev  # rehearsals with more ranks than GPUs share devices (RCCL then falls back)
     grid = hfpf.OccupancyGrid(resolution=RES, bbox=BBOX, device=device, max_bricks=400000,
                               max_log_points=min(max(n_gen, 64) * NPTS, 1 << 31), max_normals=24 << 20,
-                              max_frames=max(n_gen * max(world, 1) + 16, 4096))
+                              max_frames=max(n_gen * max(world, 1) + 16, 4096),
+                              frame_width=int(os.environ.get("HFPF_FRAME_WIDTH", W)))  # organised W x H frames: 16x16-pixel tiles
     transport = "none"
     if world > 1:
         import hfpf_dist

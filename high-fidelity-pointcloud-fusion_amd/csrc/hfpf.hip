@@ -221,6 +221,7 @@ int setup_params(hfpf_handle* h)
     if (c.K < 0 || c.K > 16) return fail(h, HFPF_ERR_BAD_CONFIG, "K out of range [0,16]");
     if (!(c.cylinder_radius > 0) || !(c.ball_radius > 0)) return fail(h, HFPF_ERR_BAD_CONFIG, "radii must be > 0");
     g.res = (double)c.resolution;  // float -> double, grid.hpp:614-619
+    g.inv_res = 1.0 / g.res;
     for (int a = 0; a < 3; a++) {
         g.min[a] = c.bbox[2 * a];
         g.max[a] = c.bbox[2 * a + 1];
@@ -430,6 +431,9 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
                         (frame_stride & 15) == 0;
     const dim3 block(256);
     const uint64_t n_tiles = (uint64_t)blocks_for(n_points, 256) * n_frames;
+    // 16x16-pixel tiles when the caller told us the image width and the frame tiles exactly (hfpf_config.frame_width)
+    const uint32_t fw = h->cfg.frame_width;
+    const uint32_t row_w = (fw >= 16 && fw % 16 == 0 && n_points % fw == 0 && (n_points / fw) % 16 == 0) ? fw : 0u;
     const dim3 grid((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)h->integrate_grid));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
@@ -479,7 +483,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     }
 #define HFPF_LAUNCH_INTEGRATE(P, C, B)                                                                                                              \
     hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay, \
-                       (const double*)s->d_pose, (const uint32_t*)s->d_ids)
+                       (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w)
     if (!bin) {
         if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, false);
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, false);

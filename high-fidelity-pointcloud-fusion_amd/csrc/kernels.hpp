@@ -96,7 +96,7 @@ template <bool PACKED16, bool COLOR, bool BIN>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
-                                                   const uint32_t* __restrict__ frame_ids)
+                                                   const uint32_t* __restrict__ frame_ids, const uint32_t row_w)
 {
     __shared__ unsigned long long queue[4][64 * kQueueStride];
     __shared__ unsigned int blk_ctr[6];
@@ -115,7 +115,15 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t f = (uint32_t)(tile / tiles_per_frame);
-        const uint32_t i = (uint32_t)(tile % tiles_per_frame) * 256u + threadIdx.x;
+        // row_w != 0 (host-checked: organised frame, width and rows multiples of 16): the tile is a 16x16-pixel patch, whose
+        // points fall into ~2x2 bricks and half as many table lines as a 256-pixel run of one image row;
+        uint32_t i = (uint32_t)(tile % tiles_per_frame) * 256u + threadIdx.x;
+        if (row_w) {
+            const uint32_t tile_in_frame = (uint32_t)(tile % tiles_per_frame), tiles_x = row_w >> 4;
+            // each wave takes one 8x8 quadrant of the patch (8 pixels x 16 B = one 128-byte line per image row)
+            const uint32_t px = ((threadIdx.x >> 6) & 1u) * 8u + (threadIdx.x & 7u), py = (threadIdx.x >> 7) * 8u + ((threadIdx.x >> 3) & 7u);
+            i = ((tile_in_frame / tiles_x) * 16u + py) * row_w + (tile_in_frame % tiles_x) * 16u + px;
+        }
         double T[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) T[k] = poses[12 * f + k];

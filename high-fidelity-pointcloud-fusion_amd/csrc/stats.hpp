@@ -46,6 +46,16 @@ __device__ __forceinline__ void stat_delta_zero(StatDeltaT<COLOR>& d)
     if constexpr (COLOR) d.rgb[0] = d.rgb[1] = d.rgb[2] = 0;
 }
 
+// Round-to-nearest-even double -> int64, bit-identical to rn_ll(x) for |x| < 2^51: adding 1.5 * 2^52 leaves the
+// rounded integer in the low mantissa bits (the sum's ulp is 1).  Every value converted here is <= 2^38 in magnitude (the
+// fixed-point scales are chosen that way at create, hfpf.hip setup_params).  Two cheap instructions instead of the six
+// f64 ones (rndne, ldexp, floor, fma, two cvt) the generic conversion expands to -- the pair loops are VALU-bound.
+__device__ __forceinline__ long long rn_ll(double x)
+{
+    const double magic = 6755399441055744.0;  // 1.5 * 2^52
+    return __double_as_longlong(x + magic) - __double_as_longlong(magic);
+}
+
 // Contribution of one cylinder member.
 template <bool COLOR>
 __device__ __forceinline__ void stat_delta_add(StatDeltaT<COLOR>& d, const GridParams& g, F3 proj, F3 c, double dist, uint32_t rgb)
@@ -54,12 +64,12 @@ __device__ __forceinline__ void stat_delta_add(StatDeltaT<COLOR>& d, const GridP
     const double oy = (double)proj.y - (double)c.y;
     const double oz = (double)proj.z - (double)c.z;
     d.v[SW_COUNT] += 1;
-    d.v[SW_S1 + 0] += __double2ll_rn(ox * g.s1_scale);
-    d.v[SW_S1 + 1] += __double2ll_rn(oy * g.s1_scale);
-    d.v[SW_S1 + 2] += __double2ll_rn(oz * g.s1_scale);
-    d.v[SW_S2] += __double2ll_rn(((ox * ox + oy * oy) + oz * oz) * g.s2_scale);
-    d.v[SW_D] += __double2ll_rn(dist * g.sd_scale);
-    d.v[SW_DD] += __double2ll_rn((dist * dist) * g.sdd_scale);
+    d.v[SW_S1 + 0] += rn_ll(ox * g.s1_scale);
+    d.v[SW_S1 + 1] += rn_ll(oy * g.s1_scale);
+    d.v[SW_S1 + 2] += rn_ll(oz * g.s1_scale);
+    d.v[SW_S2] += rn_ll(((ox * ox + oy * oy) + oz * oz) * g.s2_scale);
+    d.v[SW_D] += rn_ll(dist * g.sd_scale);
+    d.v[SW_DD] += rn_ll((dist * dist) * g.sdd_scale);
     if constexpr (COLOR) {
         d.rgb[0] += (long long)((rgb >> 16) & 255u);
         d.rgb[1] += (long long)((rgb >> 8) & 255u);

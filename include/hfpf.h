@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HFPF_ABI_VERSION 1
+#define HFPF_ABI_VERSION 2
 
 /* hfpf_config.flags */
 #define HFPF_FLAG_FUSE_COLOR 1u /* EXTENSION: also average the member points' RGB per voxel (reference: never, grid.hpp:471-479) */
@@ -69,6 +69,13 @@ typedef struct hfpf_config {
     uint64_t max_log_points;  /* points buffered while their voxel has no normal (grid.hpp:211,230) */
     uint64_t max_normals;     /* voxels that may receive a normal */
     uint64_t max_frames;      /* frame ids (viewpoint table) */
+    /* Scheduling hint, no reference counterpart: pixels per image row when every frame is a row-major organised image
+       (sensor_msgs/PointCloud2 width of an organised cloud, or the sensor's width for clouds republished as height=1);
+       0 = unknown.  The integrate kernel then walks a frame in 16x16-pixel patches instead of 256-point runs, which
+       touches about half as many voxel-table lines per point.  Used only when width and rows are multiples of 16 and
+       n_points is a multiple of width; results never depend on it. */
+    uint32_t frame_width;
+    uint32_t reserved0;       /* 0 */
 } hfpf_config;
 
 /* One emitted voxel = one line of test_cloud.pcd + one line of meta.csv (grid.hpp:466-480). 64 bytes. */
