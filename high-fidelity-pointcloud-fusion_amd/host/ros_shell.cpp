@@ -78,6 +78,7 @@ int main(int argc, char** argv)
     if (pnh.getParam("gate", iv)) p.engine.gate = iv;
     if (pnh.getParam("line_half_length", iv)) p.engine.K = iv;
     if (pnh.getParam("device", iv)) p.engine.device = iv;
+    if (pnh.getParam("frame_width", iv) && iv > 0) p.engine.frame_width = (uint32_t)iv;  // image width of the sensor: 16x16-pixel tiles (speed only)
     if (pnh.getParam("clean_period", v)) p.clean_period_s = v;
     bool flag;
     if (pnh.getParam("fuse_color", flag) && flag) p.engine.flags |= HFPF_FLAG_FUSE_COLOR;
