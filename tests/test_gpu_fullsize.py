@@ -74,6 +74,8 @@ def test_config1_stream_properties_and_reproducibility(hfpf_mod, synth_mod):
     _props(rows, ctr, dims)
     rows2, ctr2, _ = _stream(hfpf_mod, sc, 6, caps)  # different batching, same schedule
     assert rows.tobytes() == rows2.tobytes(), "not bit-reproducible across runs / batch sizes"
+    rows4, _, _ = _stream(hfpf_mod, sc, 12, dict(caps, frame_width=640))  # 16x16-pixel tiles (bench.py's setting)
+    assert rows.tobytes() == rows4.tobytes(), "frame_width hint changed the result"
     rows3, ctr3, _ = _stream(hfpf_mod, sc, 6, caps, world=3)  # frames dealt to 3 virtual ranks
     assert rows.tobytes() == rows3.tobytes(), "sharded run differs from the single-GPU run"
     assert ctr3["points_presented"] == ctr["points_presented"] and ctr3["dep_pairs_member"] + ctr3["replay_members"] == \

@@ -146,3 +146,21 @@ def test_binned_and_direct_update_are_bit_identical(oracle_mod, hfpf_mod, synth_
         ctr2 = g2.counters()
     assert got.tobytes() == other.tobytes()
     assert ctr["dep_pairs_tested"] == ctr2["dep_pairs_tested"] and ctr["dep_pairs_member"] == ctr2["dep_pairs_member"]
+
+
+@pytest.mark.parametrize("layout_name", ["LAYOUT_PACKED16", "LAYOUT_PCL32"])
+def test_frame_width_hint_changes_nothing(oracle_mod, hfpf_mod, synth_mod, layout_name):
+    """hfpf_config.frame_width only re-tiles the integrate kernel (16x16-pixel patches, one 8x8 patch per wave): rows must
+    be byte-identical with the hint, without it, and with a width that does not tile the frame (falls back to runs);
+    and the hinted run must still match the oracle."""
+    sc = scenes.Scene(5, 160, 128, 0.001, fx=615.0, clean_every=2, layout=getattr(synth_mod, layout_name))
+    rows = {}
+    for fw in (0, 160, 100, 48):  # 48: width is a multiple of 16 but 160*128/48 is not integral -> falls back
+        with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, frame_width=fw, **SMALL) as eg:
+            rows[fw] = scenes.run(eg, sc, "integrate")
+    assert len(rows[0]) > 1000
+    for fw in (160, 100, 48):
+        assert rows[fw].tobytes() == rows[0].tobytes(), "frame_width=%d changed the result" % fw
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    scenes.compare_rows(scenes.run(og, sc, "capture"), rows[160])
+    og.close()
