@@ -41,6 +41,7 @@ struct FrameLayout {
 #define HFPF_REPLAY_B 3  // registrants per chain walk held in registers by k_replay
 #endif
 constexpr int kLogRegions = 64;
+typedef float vf4 __attribute__((ext_vector_type(4)));  // native vector type (the nontemporal builtins do not take HIP's float4)
 
 // Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (7 words + record id + rgb sums)
 // in the wave's LDS queue, then the wave replays the queue with 8 lanes per record, so one wave-instruction
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         uint32_t rgb = 0;
         if (act) {
             if (PACKED16) {
-                const float4 v = reinterpret_cast<const float4*>(base)[i];
+                const vf4 nv = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(base) + i);  // read once
+                const float4 v = make_float4(nv.x, nv.y, nv.z, nv.w);
                 x = v.x;
                 y = v.y;
                 z = v.z;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
                     const uint64_t e = (uint64_t)roff + pos;
-                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)off));  // the point + where its dependant list starts
+                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)off));  // the point + where its dependant list starts; read back once by k_update
                     if (COLOR) t.bin_rgb[e] = rgb;
                     cnt = 0;  // handled by k_update
                 }
