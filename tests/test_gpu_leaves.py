@@ -41,6 +41,46 @@ def test_transform_zclip_index_bbox_bit_exact(oracle_mod, hfpf_mod, synth_mod, r
             assert np.array_equal((flags & 1) != 0, (z < 0.6) & (z > 0.28))
 
 
+@pytest.mark.parametrize("res,bbox", [
+    (0.005, (-0.80, 1.80, -1.5, 1.5, 0.0, 1.0)),
+    (0.001, (-0.5, 0.5, -0.5, 0.5, 0.0, 1.0)),
+    (0.0005, (-1.0, 1.0, -0.5, 0.5, 0.0, 1.0)),
+    (0.001, (-1.25, 1.25, -1.0, 1.0, 0.0, 2.0)),
+])
+def test_voxel_index_on_exact_cell_boundaries(oracle_mod, hfpf_mod, synth_mod, res, bbox):
+    """The device computes the index as floor(a * (1/res)) and falls back to the exact IEEE division whenever that product is
+    within 1e-6 of an integer (geometry.hpp voxel_axis).  Identity pose, coordinates ON the voxel boundaries of all three
+    axes and 0-3 f32 ulps either side, plus the bbox faces: every index must equal the oracle's floor((double(p)-min)/res)."""
+    rng = np.random.default_rng(21)
+    r = float(np.float32(res))  # the grid stores (double)(float)resolution
+    n_cells = 60000
+    pts = []
+    for a in range(3):
+        lo, hi = bbox[2 * a], bbox[2 * a + 1]
+        k = rng.integers(0, int((hi - lo) / r) + 1, size=n_cells)
+        edge = (lo + k * r).astype(np.float32)  # nearest f32 to the boundary
+        for step in range(-3, 4):
+            c = edge.copy()
+            for _ in range(abs(step)):
+                c = np.nextafter(c, np.float32(np.inf if step > 0 else -np.inf), dtype=np.float32)
+            p = np.empty((n_cells, 3), np.float32)
+            for b in range(3):
+                p[:, b] = rng.uniform(bbox[2 * b], bbox[2 * b + 1], size=n_cells).astype(np.float32)
+            p[:, a] = c
+            pts.append(p)
+    pts = np.concatenate(pts)
+    T = synth_mod.identity_pose()
+    og = oracle_mod.OracleGrid(resolution=res, bbox=bbox)
+    with hfpf_mod.OccupancyGrid(resolution=res, bbox=bbox, **TINY) as g:
+        q, idx, flags = g.probe_points(T, pts)
+        assert np.array_equal(_bits(q), _bits(pts))  # identity pose is exact
+        idx_ref, valid_ref = og.probe_index(pts)
+        assert np.array_equal(idx, idx_ref), "index differs at %d boundary points" % int(np.any(idx != idx_ref, axis=1).sum())
+        assert np.array_equal((flags & 2) != 0, valid_ref)
+    # the construction really hits both sides of boundaries: neighbouring ulp steps must land in different cells somewhere
+    assert len(np.unique(idx_ref[:, 0])) > 100
+
+
 def test_projection_membership_bit_exact(oracle_mod, hfpf_mod):
     rng = np.random.default_rng(12)
     n = 1 << 20
