@@ -83,7 +83,18 @@ def cpu_baseline(poses, seed, n_sample, all_cores=False):
                       "restatement without the reference's 24 kB reserve per voxel (%.1f s)" % (n_sample, half, how, dt)}
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Gloo and RCCL print banners on file descriptor 1 from C code, so keep a private
+    handle to the real stdout for that line and point fd 1 (and Python's sys.stdout) at stderr for everything else."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
+    return real
+
+
 def main():
+    json_out = claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1")
@@ -298,7 +309,8 @@ def main():
         if args.cpu_sample > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen))
             out["cpu_baseline_all_cores"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen), all_cores=True)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     grid.device_free(dev)
     grid.close()
     if dist is not None:

@@ -35,3 +35,21 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert d["cpu_baseline_all_cores"]["cores"] >= 1
     assert d["rows_extracted"] > 0
+
+
+def test_bench_two_ranks_one_line_on_stdout():
+    """Launched the way the driver launches N > 1 (one rank per GPU; here both ranks share the one GPU, so the RCCL
+    communicator is refused and the ranks agree to fall back to the host-staged transport).  Gloo and RCCL print banners on
+    fd 1; stdout must still carry exactly one JSON line, from rank 0."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2"],
+                         capture_output=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must be exactly one line, got %d: %r" % (len(lines), lines[:3])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak"
+    assert d["config"]["points_per_step"] == 640 * 480
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    assert d["value"] > 0 and d["rows_extracted"] > 0
