@@ -48,6 +48,21 @@ def test_identity_single_frame_config0(oracle_mod, hfpf_mod, synth_mod):
     scenes.compare_rows(ref, got)
 
 
+def test_full_resolution_frames_with_tile_hint_vs_oracle(oracle_mod, hfpf_mod, synth_mod):
+    """Three 640x480 frames with random poses, clean after the second, frame_width = 640 (bench.py's setting): the 16x16-pixel
+    tile path at the sensor's real size against the oracle."""
+    sc = scenes.Scene(3, 640, 480, 0.001, clean_every=2)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ref = scenes.run(og, sc, "capture")
+    occ_ref = og.occupied()
+    og.close()
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, frame_width=640, **SMALL) as eg:
+        got = scenes.run(eg, sc, "integrate")
+        assert np.array_equal(occ_ref, eg.occupied())
+    assert len(ref) > 100000
+    scenes.compare_rows(ref, got)
+
+
 def test_pcl32_layout(oracle_mod, hfpf_mod, synth_mod):
     """32-byte PCL-style records (x,y,z at 0,4,8; rgb at 16) through the generic decode path."""
     sc = scenes.Scene(3, 160, 120, 0.005, layout=synth_mod.LAYOUT_PCL32, clean_every=2)
