@@ -83,6 +83,11 @@ def cpu_baseline(poses, seed, n_sample, all_cores=False):
                       "restatement without the reference's 24 kB reserve per voxel (%.1f s)" % (n_sample, half, how, dt)}
 
 
+def call_frames(args):
+    """Frames handed to one hfpf_integrate_device call."""
+    return max(1, min(args.frames_per_call, int(os.environ.get("HFPF_BENCH_CALL_POINTS", 150 * 307200)) // NPTS))
+
+
 def claim_stdout():
     """The contract is ONE JSON line on stdout.  Gloo and RCCL print banners on file descriptor 1 from C code, so keep a private
     handle to the real stdout for that line and point fd 1 (and Python's sys.stdout) at stderr for everything else."""
@@ -138,7 +143,8 @@ def main():
     grid = hfpf.OccupancyGrid(resolution=RES, bbox=BBOX, device=device, max_bricks=400000,
                               max_log_points=min(max(n_gen, 64) * NPTS, 1 << 31), max_normals=24 << 20,
                               max_frames=max(n_gen * max(world, 1) + 16, 4096),
-                              frame_width=int(os.environ.get("HFPF_FRAME_WIDTH", W)))  # organised W x H frames: 16x16-pixel tiles
+                              frame_width=int(os.environ.get("HFPF_FRAME_WIDTH", W)),  # organised W x H frames: 16x16-pixel tiles
+                              max_call_points=call_frames(args) * NPTS)  # per-call bins sized at create, like the other pools
     transport = "none"
     if world > 1:
         import hfpf_dist
@@ -178,7 +184,7 @@ def main():
 
     def run_stream(n_frames, timed):
         done = 0
-        B = max(1, min(args.frames_per_call, int(os.environ.get("HFPF_BENCH_CALL_POINTS", 150 * 307200)) // NPTS))
+        B = call_frames(args)
         while done < n_frames:
             nxt = n_frames
             if args.clean_every:

@@ -847,6 +847,21 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         h->integrate_grid = std::max(1, per_cu) * std::max(1, cus);
     }
     if ((rc = alloc_tables(h))) return bail(rc);
+    {
+        // Work buffers that would otherwise grow on first use are sized here like the pools: the clean
+        // passes' key / value / sort scratch from max_normals, the per-call brick bins from max_call_points when given.
+        const uint64_t n0 = h->cfg.max_normals;
+        if ((rc = scratch(h, h->keys_a, n0 * 8)) || (rc = scratch(h, h->keys_b, n0 * 8)) || (rc = scratch(h, h->vals_a, n0 * 4)) ||
+            (rc = scratch(h, h->vals_b, n0 * 4)) || (rc = scratch(h, h->pend_b, n0 * 4)) || (rc = scratch(h, h->sort_tmp, n0 * 16)))
+            return bail(rc);
+        if (h->cfg.max_call_points && h->binned) {
+            const uint64_t pts = h->cfg.max_call_points;
+            const uint64_t pool = std::min<uint64_t>(pts + pts / 3 + 64ull * (h->cfg.max_bricks + 1), 0xFFFFFFFFull);
+            if ((rc = scratch(h, h->bin_pt_buf, pool * sizeof(float4)))) return bail(rc);
+            if (h->t.cstats && (rc = scratch(h, h->bin_rgb_buf, pool * 4))) return bail(rc);
+            h->bin_pool = pool;
+        }
+    }
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "sync after init: %s", hipGetErrorString(e)));
     *out = h;
     return HFPF_OK;

@@ -52,6 +52,7 @@ class Config(C.Structure):
         ("max_frames", C.c_uint64),
         ("frame_width", C.c_uint32),
         ("reserved0", C.c_uint32),
+        ("max_call_points", C.c_uint64),
     ]
 
 
@@ -180,7 +181,7 @@ class OccupancyGrid:
     """Device-resident occupancy grid.  Keyword defaults are the reference's constants."""
 
     def __init__(self, resolution=None, bbox=None, k=None, K=None, gate=None, cylinder_radius=None, ball_radius=None,
-                 z_clip=None, device=0, max_bricks=0, max_log_points=0, max_normals=0, max_frames=0, fuse_color=False, pcl_shifted_cov=False, binned_update=None, frame_width=0):
+                 z_clip=None, device=0, max_bricks=0, max_log_points=0, max_normals=0, max_frames=0, fuse_color=False, pcl_shifted_cov=False, binned_update=None, frame_width=0, max_call_points=0):
         L = lib()
         c = default_config()
         if resolution is not None:
@@ -203,6 +204,7 @@ class OccupancyGrid:
                    (0 if binned_update else FLAG_DIRECT_UPDATE))
         c.max_bricks, c.max_log_points, c.max_normals, c.max_frames = max_bricks, max_log_points, max_normals, max_frames
         c.frame_width = int(frame_width)  # scheduling hint only (16x16-pixel tiles); results do not depend on it
+        c.max_call_points = int(max_call_points)  # 0 = per-call bins grown on demand
         self.cfg = c
         self._transport = None
         self._h = C.c_void_p()

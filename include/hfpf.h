@@ -76,6 +76,9 @@ typedef struct hfpf_config {
        n_points is a multiple of width; results never depend on it. */
     uint32_t frame_width;
     uint32_t reserved0;       /* 0 */
+    /* Largest n_points * n_frames one hfpf_integrate_device call will carry; sizes the per-call brick bins at create like
+       the other pools.  0 = grown on demand (the first call of a new size then pays for the allocation). */
+    uint64_t max_call_points;
 } hfpf_config;
 
 /* One emitted voxel = one line of test_cloud.pcd + one line of meta.csv (grid.hpp:466-480). 64 bytes. */
