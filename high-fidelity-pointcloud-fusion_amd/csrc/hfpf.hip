@@ -1144,6 +1144,13 @@ int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128)
     h->rank = rank;
     h->world = world;
     HIPCHK(h, hipHostMalloc((void**)&h->h_counts, (size_t)(world + 1) * 8, hipHostMallocDefault));
+    {  // exchange buffers for epochs of up to 4 M newly occupied cells per rank exist from here on; larger epochs grow them
+        const uint64_t recs = std::min<uint64_t>(h->t.max_occ, 4ull << 20);
+        int rc;
+        if ((rc = scratch(h, h->ex_counts, (size_t)(world + 1) * 8)) || (rc = scratch(h, h->ex_send, recs * sizeof(EpochRec))) ||
+            (rc = scratch(h, h->ex_recv, (size_t)world * recs * sizeof(EpochRec))))
+            return rc;
+    }
     h->dist_on = true;
     return HFPF_OK;
 }
