@@ -178,6 +178,13 @@ int scratch(hfpf_handle* h, DevBuf& b, size_t bytes)
 inline unsigned blocks_for(uint64_t n, unsigned bs) { return (unsigned)std::max<uint64_t>(1, (n + bs - 1) / bs); }
 
 __global__ void k_set_ctr(unsigned long long* ctr, int idx, unsigned long long v) { ctr[idx] = v; }
+// up to three counters in one launch (the clean pass resets them in groups; a launch costs ~5 us even for one thread)
+__global__ void k_set_ctr3(unsigned long long* ctr, int i0, unsigned long long v0, int i1, unsigned long long v1, int i2, unsigned long long v2)
+{
+    ctr[i0] = v0;
+    ctr[i1] = v1;
+    if (i2 >= 0) ctr[i2] = v2;
+}
 
 int read_counters(hfpf_handle* h)
 {
@@ -689,9 +696,7 @@ int clean_locked(hfpf_handle* h)
     // candidates: the cells that failed the gate last time (pending list) + the cells occupied since (new tail of occ_list)
     const uint64_t n_new_occ = n_occ - std::min(n_occ, h->gate_done);
     if ((rc = scratch(h, h->pend_b, std::max<uint64_t>(h->n_pend + n_new_occ, 1) * 4))) return rc;
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull);
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_PEND, 0ull);
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_PRECHG, 0ull);
+    hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull, (int)C_PEND, 0ull, (int)C_PRECHG, 0ull);
     if (h->n_pend)
         hipLaunchKernelGGL(k_gate, dim3(blocks_for(h->n_pend, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->pend_a.p, h->n_pend, (uint32_t*)h->pend_b.p);
     if (n_new_occ)
@@ -714,8 +719,7 @@ int clean_locked(hfpf_handle* h)
     hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_cand, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, n_cand, n_normals);
     const uint64_t n_steps = (((n_cand + 255) / 256) * 256) * (2ull * (uint64_t)h->g.K + 1ull);  // step-major, block-aligned
     hipLaunchKernelGGL(k_register, dim3(blocks_for(n_steps, 256)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand));
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_TOUCHED, 0ull);
+    hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand), (int)C_TOUCHED, 0ull, -1, 0ull);
     HIPCHK(h, hipGetLastError());
     if ((rc = read_counters(h))) return rc;
     if ((rc = check_device_errors(h))) return rc;
@@ -750,8 +754,7 @@ int clean_locked(hfpf_handle* h)
     if (full) {
         const uint64_t n_all = n_reg + n_pre;
         if (n_all > t.max_dep) return fail(h, HFPF_ERR_CAPACITY, "dependant table: %llu entries > %llu", (unsigned long long)n_all, (unsigned long long)t.max_dep);
-        hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_DEP, 0ull);
-        hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_TOUCHED, 0ull);
+        hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_DEP, 0ull, (int)C_TOUCHED, 0ull, -1, 0ull);
         if (n_all) {
             hipLaunchKernelGGL(k_dep_count, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
             HIPCHK(h, hipGetLastError());
