@@ -717,8 +717,9 @@ int clean_locked(hfpf_handle* h)
     if ((rc = scratch(h, h->keys_a, n_cand * 8))) return rc;
     if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_cand))) return rc;
     hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_cand, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, n_cand, n_normals);
-    const uint64_t n_steps = (((n_cand + 255) / 256) * 256) * (2ull * (uint64_t)h->g.K + 1ull);  // step-major, block-aligned
-    hipLaunchKernelGGL(k_register, dim3(blocks_for(n_steps, 256)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
+    const uint64_t reg_tile = 256ull * kRegTiles;  // step-major, whole workgroups (kRegTiles tiles each) per step
+    const uint64_t reg_blocks = ((n_cand + reg_tile - 1) / reg_tile) * (2ull * (uint64_t)h->g.K + 1ull);
+    hipLaunchKernelGGL(k_register, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
     hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand), (int)C_TOUCHED, 0ull, -1, 0ull);
     HIPCHK(h, hipGetLastError());
     if ((rc = read_counters(h))) return rc;

@@ -41,6 +41,10 @@ struct FrameLayout {
 #define HFPF_REPLAY_B 3  // registrants per chain walk held in registers by k_replay
 #endif
 constexpr int kLogRegions = 64;
+#ifndef HFPF_REG_TILES
+#define HFPF_REG_TILES 8  // 256-voxel tiles one workgroup of k_register takes per list reservation
+#endif
+constexpr int kRegTiles = HFPF_REG_TILES;
 typedef float vf4 __attribute__((ext_vector_type(4)));  // native vector type (the nontemporal builtins do not take HIP's float4)
 
 // Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (7 words + record id + rgb sums)
@@ -549,54 +553,70 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
 // record ids, which ascend with the canonical key order inside a pass and across passes.
 __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand, const uint64_t base)
 {
-    // step-major mapping: a wave holds 64 key-adjacent voxels at the SAME step, so its targets sit in the same few bricks
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Step-major mapping: a wave holds 64 key-adjacent voxels at the SAME step, so its targets sit in the same few bricks.
+    // A workgroup takes kRegTiles consecutive 256-voxel tiles of one step and reserves its list entries once per list: the
+    // three list counters share a line, and same-line device atomics retire one per ~12 ns whoever issues them.
     const uint32_t steps = 2u * (uint32_t)g.K + 1u;
-    const uint64_t per_step = ((n_cand + 255) / 256) * 256;  // whole blocks per step keep waves uniform in i
-    const uint64_t r = idx % per_step;
-    const int i = (int)(idx / per_step) - g.K;
-    bool want = r < n_cand && (idx / per_step) < steps;
-    uint64_t nid = 0;
-    F3 c = {0, 0, 0}, n = {0, 0, 0};
-    int32_t xx = 0, yy = 0, zz = 0;
-    if (want) {
-        nid = base + r + 1;
-        c = F3{t.nv_c[3 * nid], t.nv_c[3 * nid + 1], t.nv_c[3 * nid + 2]};
-        n = F3{t.nv_n[3 * nid], t.nv_n[3 * nid + 1], t.nv_n[3 * nid + 2]};
-        const F3 nb = line_step(g, c, n, i);  // grid.hpp:405
-        want = valid_point(g, nb);            // grid.hpp:406
-        voxel_coords(g, nb, xx, yy, zz);      // grid.hpp:409
-        want = want && xx != INT_MIN && yy != INT_MIN && zz != INT_MIN && valid_coord(g, xx, yy, zz);  // grid.hpp:410
+    const uint64_t tile_items = 256ull * kRegTiles;
+    const uint64_t per_step = ((n_cand + tile_items - 1) / tile_items) * tile_items;  // whole workgroups per step keep them uniform in i
+    const uint64_t blk_first = (uint64_t)blockIdx.x * tile_items;
+    const uint32_t step_idx = (uint32_t)(blk_first / per_step);
+    const int i = (int)step_idx - g.K;
+    uint32_t slot_[kRegTiles], nid_[kRegTiles];
+    uint32_t f_occ = 0, f_new = 0, f_chg = 0;
+#pragma unroll
+    for (int tt = 0; tt < kRegTiles; tt++) {
+        const uint64_t r = blk_first % per_step + (uint64_t)tt * 256u + threadIdx.x;
+        bool want = r < n_cand && step_idx < steps;
+        uint64_t nid = 0;
+        int32_t xx = 0, yy = 0, zz = 0;
+        if (want) {
+            nid = base + r + 1;
+            const F3 c = F3{t.nv_c[3 * nid], t.nv_c[3 * nid + 1], t.nv_c[3 * nid + 2]};
+            const F3 n = F3{t.nv_n[3 * nid], t.nv_n[3 * nid + 1], t.nv_n[3 * nid + 2]};
+            const F3 nb = line_step(g, c, n, i);  // grid.hpp:405
+            want = valid_point(g, nb);            // grid.hpp:406
+            voxel_coords(g, nb, xx, yy, zz);      // grid.hpp:409
+            want = want && xx != INT_MIN && yy != INT_MIN && zz != INT_MIN && valid_coord(g, xx, yy, zz);  // grid.hpp:410
+        }
+        const uint32_t bidx = want ? brick_index(g, xx, yy, zz) : 0u;
+        const uint32_t b = brick_acquire_wave(t, bidx, want);
+        want = want && b != 0;
+        const uint32_t slot = b * kBrickCells + local_index(xx, yy, zz);
+        const bool occ = want && (t.info[slot] & kOcc);
+        slot_[tt] = slot;
+        nid_[tt] = (uint32_t)nid;
+        if (occ) f_occ |= 1u << tt;
+        if (want && !occ) {
+            const uint32_t old = atomicMax(&t.pre_dep[slot], (uint32_t)nid);
+            if (old == 0u) f_new |= 1u << tt;    // first registration ever on this cell
+            if (old <= base) f_chg |= 1u << tt;  // first change in THIS pass (ids of this pass are > base): exactly one lane sees it
+        }
     }
-    const uint32_t bidx = want ? brick_index(g, xx, yy, zz) : 0u;
-    const uint32_t b = brick_acquire_wave(t, bidx, want);
-    want = want && b != 0;
-    const uint32_t slot = b * kBrickCells + local_index(xx, yy, zz);
-    const bool occ = want && (t.info[slot] & kOcc);
-    const bool unocc = want && !occ;
-
     __shared__ BlockReserveScratch brs;
-    const unsigned long long ri = block_reserve(&t.ctr[C_REG], occ, brs);
-    if (occ) {
-        if (ri < t.max_reg) t.reg_occ[ri] = make_uint2(slot, (uint32_t)nid);  // dependants.push_back, grid.hpp:417
-        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
+    unsigned long long ri = block_reserve_n(&t.ctr[C_REG], (uint32_t)__popc(f_occ), brs);
+    unsigned long long pi = block_reserve_n(&t.ctr[C_PREREG], (uint32_t)__popc(f_new), brs);
+    unsigned long long ci = block_reserve_n(&t.ctr[C_PRECHG], (uint32_t)__popc(f_chg), brs);
+    bool overflow = false;
+#pragma unroll
+    for (int tt = 0; tt < kRegTiles; tt++) {
+        if (f_occ & (1u << tt)) {
+            if (ri < t.max_reg) t.reg_occ[ri] = make_uint2(slot_[tt], nid_[tt]);  // dependants.push_back, grid.hpp:417
+            else overflow = true;
+            ri++;
+        }
+        if (f_new & (1u << tt)) {
+            if (pi < t.max_reg) t.prereg_list[pi] = slot_[tt];
+            else overflow = true;
+            pi++;
+        }
+        if (f_chg & (1u << tt)) {
+            if (ci < t.max_reg) t.prechg_list[ci] = slot_[tt];
+            else overflow = true;
+            ci++;
+        }
     }
-    bool newpre = false, chgpre = false;
-    if (unocc) {
-        const uint32_t old = atomicMax(&t.pre_dep[slot], (uint32_t)nid);
-        newpre = old == 0u;        // first registration ever on this cell
-        chgpre = old <= base;      // first change in THIS pass (ids of this pass are > base): exactly one lane sees it
-    }
-    const unsigned long long pi = block_reserve(&t.ctr[C_PREREG], newpre, brs);
-    if (newpre) {
-        if (pi < t.max_reg) t.prereg_list[pi] = slot;
-        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
-    }
-    const unsigned long long ci = block_reserve(&t.ctr[C_PRECHG], chgpre, brs);
-    if (chgpre) {
-        if (ci < t.max_reg) t.prechg_list[ci] = slot;
-        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
-    }
+    if (overflow) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
 }
 
 // K5b: buffer replay (grid.hpp:418-440), cell-centric.  The reference replays a cell's buffer once per voxel that

@@ -276,6 +276,32 @@ __device__ inline unsigned long long block_reserve(unsigned long long* ctr, bool
     return r;
 }
 
+// Block-aggregated reservation of a per-thread amount n: ONE device atomic per workgroup of 256 threads; returns the first
+// index of the calling thread's n entries.  Convergent (contains barriers).
+__device__ inline unsigned long long block_reserve_n(unsigned long long* ctr, uint32_t n, BlockReserveScratch& s)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63) s.wave_cnt[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s.wave_cnt[0] + s.wave_cnt[1] + s.wave_cnt[2] + s.wave_cnt[3];
+        s.base = total ? atomicAdd(ctr, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    uint32_t prefix = 0;
+    for (uint32_t w = 0; w < wave; w++) prefix += s.wave_cnt[w];
+    const unsigned long long r = s.base + prefix + (unsigned long long)(incl - n);
+    __syncthreads();  // scratch may be reused by the next call
+    return r;
+}
+
 // Wave-aggregated reservation of a per-lane amount n (0 for idle lanes): one atomic per wave, exclusive
 // prefix sum across the lanes.  Convergent.
 __device__ inline unsigned long long wave_reserve_n(unsigned long long* ctr, uint32_t n)
