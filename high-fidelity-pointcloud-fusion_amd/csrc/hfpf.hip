@@ -733,16 +733,16 @@ int clean_locked(hfpf_handle* h)
     bool full = h->h_ctr[C_DEP] + 8 * n_new + n_chg > t.max_dep;
     if (!full) {
         if (n_new) {
-            hipLaunchKernelGGL(k_depinc_count, dim3(blocks_for(n_new, 256)), dim3(256), 0, s, t, h->reg_done, n_reg);
+            hipLaunchKernelGGL(k_depinc_count, dim3(blocks_for(n_new, 256 * kListTiles)), dim3(256), 0, s, t, h->reg_done, n_reg);
             HIPCHK(h, hipGetLastError());
             if ((rc = read_counters(h))) return rc;
             const uint64_t n_touched = h->h_ctr[C_TOUCHED];
-            hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
+            hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(n_touched, 256 * kListTiles)), dim3(256), 0, s, t, n_touched);
             hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(n_new, 256)), dim3(256), 0, s, t, h->reg_done, n_reg);
             hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
             inc_touched = n_touched;
         }
-        if (n_chg) hipLaunchKernelGGL(k_depinc_pre, dim3(blocks_for(n_chg, 256)), dim3(256), 0, s, t, n_chg);
+        if (n_chg) hipLaunchKernelGGL(k_depinc_pre, dim3(blocks_for(n_chg, 256 * kListTiles)), dim3(256), 0, s, t, n_chg);
         HIPCHK(h, hipGetLastError());
         if ((rc = read_counters(h))) return rc;
         if (h->h_ctr[C_ERR] == (unsigned long long)E_DEP) {  // dep[] ran out mid-way: compact

@@ -45,6 +45,7 @@ constexpr int kLogRegions = 64;
 #define HFPF_REG_TILES 8  // 256-voxel tiles one workgroup of k_register takes per list reservation
 #endif
 constexpr int kRegTiles = HFPF_REG_TILES;
+constexpr int kListTiles = 4;  // same idea for the k_depinc_* list builders (not k_gate: it is latency-heavy per cell and needs every workgroup it can get)
 typedef float vf4 __attribute__((ext_vector_type(4)));  // native vector type (the nontemporal builtins do not take HIP's float4)
 
 // Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (7 words + record id + rgb sums)
@@ -801,45 +802,64 @@ __device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid
 
 __global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg)
 {
-    const uint64_t j = reg_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool fresh = false;
-    uint32_t slot = 0;
-    if (j < n_reg) {
-        slot = t.reg_occ[j].x;
-        fresh = atomicAdd(&t.dep_tmp[slot], 1u) == 0u;
+    uint32_t slot_[kListTiles];
+    uint32_t f_fresh = 0;
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++) {
+        const uint64_t j = reg_first + ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        slot_[tt] = 0;
+        if (j < n_reg) {
+            slot_[tt] = t.reg_occ[j].x;
+            if (atomicAdd(&t.dep_tmp[slot_[tt]], 1u) == 0u) f_fresh |= 1u << tt;
+        }
     }
     __shared__ BlockReserveScratch brs;
-    const unsigned long long ti = block_reserve(&t.ctr[C_TOUCHED], fresh, brs);
-    if (fresh) t.touched_list[ti] = slot;
+    unsigned long long ti = block_reserve_n(&t.ctr[C_TOUCHED], (uint32_t)__popc(f_fresh), brs);
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++)
+        if (f_fresh & (1u << tt)) t.touched_list[ti++] = slot_[tt];
 }
 
 __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = j < n_touched;
-    uint32_t slot = 0, old_cnt = 0, new_cnt = 0;
-    uint64_t info = 0, old_off = 0;
-    if (act) {
-        slot = t.touched_list[j];
-        info = t.info[slot];
-        old_cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-        old_off = info >> kDepOffShift;
-        new_cnt = old_cnt + t.dep_tmp[slot];
+    uint32_t slot_[kListTiles], old_cnt_[kListTiles], new_cnt_[kListTiles];
+    uint64_t info_[kListTiles];
+    uint32_t want = 0;
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        slot_[tt] = 0, old_cnt_[tt] = 0, new_cnt_[tt] = 0, info_[tt] = 0;
+        if (j < n_touched) {
+            slot_[tt] = t.touched_list[j];
+            info_[tt] = t.info[slot_[tt]];
+            old_cnt_[tt] = (uint32_t)((info_[tt] >> kDepCntShift) & kDepCntMask);
+            new_cnt_[tt] = old_cnt_[tt] + t.dep_tmp[slot_[tt]];
+            want += new_cnt_[tt];
+        }
     }
-    const unsigned long long new_off = wave_reserve_n(&t.ctr[C_DEP], new_cnt);  // one atomic per wave on the hot counter
-    if (!act) return;
-    if (new_off + new_cnt > t.max_dep || new_cnt > kDepCntMask) {  // host falls back to a full (compacting) rebuild
-        atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
-        t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
-        return;
+    __shared__ BlockReserveScratch brs;
+    unsigned long long new_off = block_reserve_n(&t.ctr[C_DEP], want, brs);  // one atomic per workgroup on the hot counter
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        if (j >= n_touched) continue;
+        const uint32_t slot = slot_[tt], old_cnt = old_cnt_[tt], new_cnt = new_cnt_[tt];
+        const uint64_t info = info_[tt], old_off = info >> kDepOffShift;
+        const unsigned long long off = new_off;
+        new_off += new_cnt;
+        if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask) {  // host falls back to a full (compacting) rebuild
+            atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
+            t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
+            continue;
+        }
+        for (uint32_t k = 0; k < old_cnt; k++) {
+            DepEntry e = t.dep[old_off + k];
+            if (k == 0) e.pad = new_cnt;  // the first entry carries the list length
+            t.dep[off + k] = e;
+        }
+        t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
+        t.dep_tmp[slot] = old_cnt;  // append cursor
     }
-    for (uint32_t k = 0; k < old_cnt; k++) {
-        DepEntry e = t.dep[old_off + k];
-        if (k == 0) e.pad = new_cnt;  // the first entry carries the list length
-        t.dep[new_off + k] = e;
-    }
-    t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)new_off << kDepOffShift);
-    t.dep_tmp[slot] = old_cnt;  // append cursor
 }
 
 __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint64_t reg_first, const uint64_t n_reg)
@@ -856,29 +876,38 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
 // Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).
 __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64_t n_chg)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = j < n_chg;
-    uint32_t slot = 0;
-    uint64_t info = 0;
-    bool fresh = false;
-    if (act) {
-        slot = t.prechg_list[j];
-        info = t.info[slot];
-        fresh = ((info >> kDepCntShift) & kDepCntMask) == 0;
+    uint32_t slot_[kListTiles];
+    uint64_t info_[kListTiles];
+    uint32_t f_fresh = 0;
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        slot_[tt] = 0, info_[tt] = 0;
+        if (j < n_chg) {
+            slot_[tt] = t.prechg_list[j];
+            info_[tt] = t.info[slot_[tt]];
+            if (((info_[tt] >> kDepCntShift) & kDepCntMask) == 0) f_fresh |= 1u << tt;
+        }
     }
     __shared__ BlockReserveScratch brs;
-    const unsigned long long noff = block_reserve(&t.ctr[C_DEP], fresh, brs);
-    if (!act) return;
-    uint64_t off = info >> kDepOffShift;
-    if (fresh) {
-        off = noff;
-        if (off >= t.max_dep) {
-            atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEP);
-            return;
+    unsigned long long noff = block_reserve_n(&t.ctr[C_DEP], (uint32_t)__popc(f_fresh), brs);
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        if (j >= n_chg) continue;
+        const uint32_t slot = slot_[tt];
+        const uint64_t info = info_[tt];
+        uint64_t off = info >> kDepOffShift;
+        if (f_fresh & (1u << tt)) {
+            off = noff++;
+            if (off >= t.max_dep) {
+                atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEP);
+                continue;
+            }
+            t.info[slot] = (info & 3ull) | (1ull << kDepCntShift) | (off << kDepOffShift);
         }
-        t.info[slot] = (info & 3ull) | (1ull << kDepCntShift) | (off << kDepOffShift);
+        t.dep[off] = make_dep_entry(t, t.pre_dep[slot], 1u);
     }
-    t.dep[off] = make_dep_entry(t, t.pre_dep[slot], 1u);
 }
 
 // ---- K6 extract -----------------------------------------------------------------------------------
