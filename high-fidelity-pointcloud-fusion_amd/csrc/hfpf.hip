@@ -621,7 +621,7 @@ int epoch_export_locked(hfpf_handle* h, uint64_t* n_out, uint64_t min_capacity_r
 int epoch_import_locked(hfpf_handle* h, const void* dev_records, uint64_t n)
 {
     if (n == 0) return HFPF_OK;
-    hipLaunchKernelGGL(k_epoch_import, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, h->t, (const EpochRec*)dev_records, n);
+    hipLaunchKernelGGL(k_epoch_import, dim3(blocks_for(n, 256 * kRegTiles)), dim3(256), 0, h->stream, h->g, h->t, (const EpochRec*)dev_records, n);
     HIPCHK(h, hipGetLastError());
     return HFPF_OK;
 }

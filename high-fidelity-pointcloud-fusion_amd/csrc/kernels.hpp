@@ -98,6 +98,25 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+constexpr int kOccStage = 1024;  // newly occupied cells a workgroup of k_integrate stages before appending them to occ_list
+// Append the staged slots with ONE atomic on C_OCC.  Convergent: every thread of the workgroup calls it (contains barriers).
+__device__ __forceinline__ void flush_occ_stage(const Tables& t, uint32_t* s_occ, unsigned int& s_occ_n, unsigned long long& s_base)
+{
+    const uint32_t n = s_occ_n;
+    if (threadIdx.x == 0) s_base = atomicAdd(&t.ctr[C_OCC], (unsigned long long)n);
+    __syncthreads();
+    bool overflow = false;
+    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+        const unsigned long long oi = s_base + k;
+        if (oi < t.max_occ) t.occ_list[oi] = s_occ[k];
+        else overflow = true;
+    }
+    if (overflow) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
+    __syncthreads();
+    if (threadIdx.x == 0) s_occ_n = 0;
+    __syncthreads();
+}
+
 template <bool PACKED16, bool COLOR, bool BIN>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
@@ -106,11 +125,15 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 {
     __shared__ unsigned long long queue[4][64 * kQueueStride];
     __shared__ unsigned int blk_ctr[6];
-    __shared__ BlockReserveScratch brs;
+    __shared__ uint32_t s_occ[kOccStage];
+    __shared__ unsigned int s_occ_n;
+    __shared__ unsigned long long s_occ_base;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     unsigned long long* q = queue[wave];
     if (threadIdx.x < 6) blk_ctr[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_occ_n = 0;
+    __syncthreads();
 
     const uint32_t tiles_per_frame = (n_pts + 255u) >> 8;
     const uint64_t n_tiles = (uint64_t)tiles_per_frame * n_frames;
@@ -183,13 +206,11 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             if (first) atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (ix & 7)]),
                                 1ull << (((iy & 7) << 3) | (iz & 7)));
         }
-        if (__syncthreads_or(first)) {  // block-uniform (tiles are dealt per block): one device atomic per block on the hot counter
-            const unsigned long long oi = block_reserve(&t.ctr[C_OCC], first, brs);
-            if (first) {
-                if (oi < t.max_occ) t.occ_list[oi] = slot;
-                else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
-            }
-        }
+        // newly occupied cells are staged in LDS and appended to occ_list in batches: C_OCC is one address for the whole
+        // chip (a same-address atomic retires every ~12 ns), so it gets one atomic per flush, not one per tile
+        if (first) s_occ[atomicAdd(&s_occ_n, 1u)] = slot;
+        __syncthreads();
+        if (s_occ_n > (unsigned)(kOccStage - 256)) flush_occ_stage(t, s_occ, s_occ_n, s_occ_base);  // block-uniform
 
         // buffer while the voxel has no normal (grid.hpp:210-211,230,239); the viewpoint latch (smallest frame
         // id that touched the cell, grid.hpp:229,238) is only ever read before the normal exists.
@@ -274,6 +295,8 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             wave_flush_members(t, q, member, d, sid);
         }
     }
+    __syncthreads();
+    if (s_occ_n) flush_occ_stage(t, s_occ, s_occ_n, s_occ_base);  // block-uniform
     // block-level reduction of the diagnostics: one device atomic per counter per block
     uint32_t cv[6] = {c_present, c_z, c_in, c_buf, c_tested, c_member};
 #pragma unroll
@@ -1029,40 +1052,54 @@ __global__ __launch_bounds__(256) void k_epoch_export(const GridParams g, const 
 
 __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const Tables t, const EpochRec* __restrict__ in, const uint64_t n)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool want = j < n;
-    EpochRec r;
-    r.key = 0;
-    r.first_frame = kNoFrame;
-    r.vx = r.vy = r.vz = 0.f;
-    int32_t x = 0, y = 0, z = 0;
-    if (want) {
-        r = in[j];
-        key_coords(r.key, x, y, z);
-        want = x <= g.dim[0] && y <= g.dim[1] && z <= g.dim[2];  // storage extent is dim+1 (grid.hpp:626)
-    }
-    const uint32_t bidx = want ? brick_index(g, x, y, z) : 0u;
-    const uint32_t b = brick_acquire_wave(t, bidx, want);
-    want = want && b != 0;
-    const uint32_t slot = b * kBrickCells + local_index(x, y, z);
-    bool first = false;
-    if (want) {
-        const unsigned int old = atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
-        first = !(old & 1u);
-        if (first) atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (x & 7)]), 1ull << (((y & 7) << 3) | (z & 7)));
-        if (r.first_frame < t.max_frames) {
-            atomicMin(&t.first_frame[slot], r.first_frame);
-            t.frame_vp[3 * (uint64_t)r.first_frame] = r.vx;  // same value from every exporter
-            t.frame_vp[3 * (uint64_t)r.first_frame + 1] = r.vy;
-            t.frame_vp[3 * (uint64_t)r.first_frame + 2] = r.vz;
+    // kRegTiles tiles per workgroup, one occ_list reservation (hot counter: see k_register)
+    uint32_t slot_[kRegTiles];
+    uint32_t f_first = 0;
+#pragma unroll
+    for (int tt = 0; tt < kRegTiles; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kRegTiles + tt) * 256u + threadIdx.x;
+        bool want = j < n;
+        EpochRec r;
+        r.key = 0;
+        r.first_frame = kNoFrame;
+        r.vx = r.vy = r.vz = 0.f;
+        int32_t x = 0, y = 0, z = 0;
+        if (want) {
+            r = in[j];
+            key_coords(r.key, x, y, z);
+            want = x <= g.dim[0] && y <= g.dim[1] && z <= g.dim[2];  // storage extent is dim+1 (grid.hpp:626)
+        }
+        const uint32_t bidx = want ? brick_index(g, x, y, z) : 0u;
+        const uint32_t b = brick_acquire_wave(t, bidx, want);
+        want = want && b != 0;
+        const uint32_t slot = b * kBrickCells + local_index(x, y, z);
+        slot_[tt] = slot;
+        if (want) {
+            const unsigned int old = atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
+            if (!(old & 1u)) {
+                f_first |= 1u << tt;
+                atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (x & 7)]), 1ull << (((y & 7) << 3) | (z & 7)));
+            }
+            if (r.first_frame < t.max_frames) {
+                atomicMin(&t.first_frame[slot], r.first_frame);
+                t.frame_vp[3 * (uint64_t)r.first_frame] = r.vx;  // same value from every exporter
+                t.frame_vp[3 * (uint64_t)r.first_frame + 1] = r.vy;
+                t.frame_vp[3 * (uint64_t)r.first_frame + 2] = r.vz;
+            }
         }
     }
     __shared__ BlockReserveScratch brs;
-    const unsigned long long oi = block_reserve(&t.ctr[C_OCC], first, brs);
-    if (first) {
-        if (oi < t.max_occ) t.occ_list[oi] = slot;
-        else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
+    unsigned long long oi = block_reserve_n(&t.ctr[C_OCC], (uint32_t)__popc(f_first), brs);
+    bool overflow = false;
+#pragma unroll
+    for (int tt = 0; tt < kRegTiles; tt++) {
+        if (f_first & (1u << tt)) {
+            if (oi < t.max_occ) t.occ_list[oi] = slot_[tt];
+            else overflow = true;
+            oi++;
+        }
     }
+    if (overflow) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
 }
 
 __global__ __launch_bounds__(256) void k_add_u64(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, const uint64_t n)
