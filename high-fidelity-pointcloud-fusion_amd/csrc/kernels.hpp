@@ -617,27 +617,32 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
             if (old <= base) f_chg |= 1u << tt;  // first change in THIS pass (ids of this pass are > base): exactly one lane sees it
         }
     }
-    __shared__ BlockReserveScratch brs;
-    unsigned long long ri = block_reserve_n(&t.ctr[C_REG], (uint32_t)__popc(f_occ), brs);
-    unsigned long long pi = block_reserve_n(&t.ctr[C_PREREG], (uint32_t)__popc(f_new), brs);
-    unsigned long long ci = block_reserve_n(&t.ctr[C_PRECHG], (uint32_t)__popc(f_chg), brs);
+    __shared__ TileReserveScratch<kRegTiles> trs;
+    uint32_t n_occ[kRegTiles], n_new[kRegTiles], n_chg[kRegTiles];
+    unsigned long long ri[kRegTiles], pi[kRegTiles], ci[kRegTiles];
+#pragma unroll
+    for (int tt = 0; tt < kRegTiles; tt++) {
+        n_occ[tt] = (f_occ >> tt) & 1u;
+        n_new[tt] = (f_new >> tt) & 1u;
+        n_chg[tt] = (f_chg >> tt) & 1u;
+    }
+    block_reserve_tiles<kRegTiles>(&t.ctr[C_REG], n_occ, ri, trs);
+    block_reserve_tiles<kRegTiles>(&t.ctr[C_PREREG], n_new, pi, trs);
+    block_reserve_tiles<kRegTiles>(&t.ctr[C_PRECHG], n_chg, ci, trs);
     bool overflow = false;
 #pragma unroll
     for (int tt = 0; tt < kRegTiles; tt++) {
-        if (f_occ & (1u << tt)) {
-            if (ri < t.max_reg) t.reg_occ[ri] = make_uint2(slot_[tt], nid_[tt]);  // dependants.push_back, grid.hpp:417
+        if (n_occ[tt]) {
+            if (ri[tt] < t.max_reg) t.reg_occ[ri[tt]] = make_uint2(slot_[tt], nid_[tt]);  // dependants.push_back, grid.hpp:417
             else overflow = true;
-            ri++;
         }
-        if (f_new & (1u << tt)) {
-            if (pi < t.max_reg) t.prereg_list[pi] = slot_[tt];
+        if (n_new[tt]) {
+            if (pi[tt] < t.max_reg) t.prereg_list[pi[tt]] = slot_[tt];
             else overflow = true;
-            pi++;
         }
-        if (f_chg & (1u << tt)) {
-            if (ci < t.max_reg) t.prechg_list[ci] = slot_[tt];
+        if (n_chg[tt]) {
+            if (ci[tt] < t.max_reg) t.prechg_list[ci[tt]] = slot_[tt];
             else overflow = true;
-            ci++;
         }
     }
     if (overflow) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
@@ -836,18 +841,21 @@ __global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint
             if (atomicAdd(&t.dep_tmp[slot_[tt]], 1u) == 0u) f_fresh |= 1u << tt;
         }
     }
-    __shared__ BlockReserveScratch brs;
-    unsigned long long ti = block_reserve_n(&t.ctr[C_TOUCHED], (uint32_t)__popc(f_fresh), brs);
+    __shared__ TileReserveScratch<kListTiles> trs;
+    uint32_t n_f[kListTiles];
+    unsigned long long ti[kListTiles];
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++) n_f[tt] = (f_fresh >> tt) & 1u;
+    block_reserve_tiles<kListTiles>(&t.ctr[C_TOUCHED], n_f, ti, trs);  // tile-major: neighbouring registrations stay neighbours
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++)
-        if (f_fresh & (1u << tt)) t.touched_list[ti++] = slot_[tt];
+        if (n_f[tt]) t.touched_list[ti[tt]] = slot_[tt];
 }
 
 __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched)
 {
     uint32_t slot_[kListTiles], old_cnt_[kListTiles], new_cnt_[kListTiles];
     uint64_t info_[kListTiles];
-    uint32_t want = 0;
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
         const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
@@ -857,19 +865,18 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
             info_[tt] = t.info[slot_[tt]];
             old_cnt_[tt] = (uint32_t)((info_[tt] >> kDepCntShift) & kDepCntMask);
             new_cnt_[tt] = old_cnt_[tt] + t.dep_tmp[slot_[tt]];
-            want += new_cnt_[tt];
         }
     }
-    __shared__ BlockReserveScratch brs;
-    unsigned long long new_off = block_reserve_n(&t.ctr[C_DEP], want, brs);  // one atomic per workgroup on the hot counter
+    __shared__ TileReserveScratch<kListTiles> trs;
+    unsigned long long off_[kListTiles];
+    block_reserve_tiles<kListTiles>(&t.ctr[C_DEP], new_cnt_, off_, trs);  // one atomic per workgroup; lists of neighbouring cells stay adjacent
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
         const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
         if (j >= n_touched) continue;
         const uint32_t slot = slot_[tt], old_cnt = old_cnt_[tt], new_cnt = new_cnt_[tt];
         const uint64_t info = info_[tt], old_off = info >> kDepOffShift;
-        const unsigned long long off = new_off;
-        new_off += new_cnt;
+        const unsigned long long off = off_[tt];
         if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask) {  // host falls back to a full (compacting) rebuild
             atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
             t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
@@ -912,8 +919,12 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
             if (((info_[tt] >> kDepCntShift) & kDepCntMask) == 0) f_fresh |= 1u << tt;
         }
     }
-    __shared__ BlockReserveScratch brs;
-    unsigned long long noff = block_reserve_n(&t.ctr[C_DEP], (uint32_t)__popc(f_fresh), brs);
+    __shared__ TileReserveScratch<kListTiles> trs;
+    uint32_t n_f[kListTiles];
+    unsigned long long noff[kListTiles];
+#pragma unroll
+    for (int tt = 0; tt < kListTiles; tt++) n_f[tt] = (f_fresh >> tt) & 1u;
+    block_reserve_tiles<kListTiles>(&t.ctr[C_DEP], n_f, noff, trs);
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
         const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
@@ -922,7 +933,7 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
         const uint64_t info = info_[tt];
         uint64_t off = info >> kDepOffShift;
         if (f_fresh & (1u << tt)) {
-            off = noff++;
+            off = noff[tt];
             if (off >= t.max_dep) {
                 atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEP);
                 continue;

@@ -302,6 +302,50 @@ __device__ inline unsigned long long block_reserve_n(unsigned long long* ctr, ui
     return r;
 }
 
+// The same for T tiles per thread, handing the indices out in tile-major order (tile, then wave, then lane) -- the order T
+// separate workgroups would have produced -- so neighbouring items stay neighbours in the list.  n[tt] = amount of the
+// calling thread for tile tt; idx[tt] = first index of that amount.  ONE device atomic.  Convergent (contains barriers).
+template <int T>
+struct TileReserveScratch {
+    uint32_t cnt[T][4];
+    unsigned long long base;
+};
+template <int T>
+__device__ inline void block_reserve_tiles(unsigned long long* ctr, const uint32_t (&n)[T], unsigned long long (&idx)[T], TileReserveScratch<T>& s)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t excl[T];
+#pragma unroll
+    for (int tt = 0; tt < T; tt++) {
+        uint32_t incl = n[tt];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        excl[tt] = incl - n[tt];
+        if (lane == 63) s.cnt[tt][wave] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int tt = 0; tt < T; tt++) total += s.cnt[tt][0] + s.cnt[tt][1] + s.cnt[tt][2] + s.cnt[tt][3];
+        s.base = total ? atomicAdd(ctr, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long run = s.base;
+#pragma unroll
+    for (int tt = 0; tt < T; tt++) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += s.cnt[tt][w];
+        idx[tt] = run + before + excl[tt];
+        run += s.cnt[tt][0] + s.cnt[tt][1] + s.cnt[tt][2] + s.cnt[tt][3];
+    }
+    __syncthreads();  // scratch may be reused by the next call
+}
+
 // Wave-aggregated reservation of a per-lane amount n (0 for idle lanes): one atomic per wave, exclusive
 // prefix sum across the lanes.  Convergent.
 __device__ inline unsigned long long wave_reserve_n(unsigned long long* ctr, uint32_t n)
