@@ -194,6 +194,9 @@ int read_counters(hfpf_handle* h)
     unsigned long long total = 0;
     for (int r = 0; r < kLogRegions; r++) total += std::min<unsigned long long>(h->h_log_ctr[r * 16], h->t.log_region_cap);
     h->h_ctr[C_LOG] = total;
+    unsigned long long replayed = 0;  // striped diagnostic counter of k_replay (word 1 of every log_ctr line)
+    for (int r = 0; r < kLogRegions; r++) replayed += h->h_log_ctr[r * 16 + 1];
+    h->h_ctr[C_REPLAY_MEMBER] = replayed;
     h->n_bricks_known = std::min<uint64_t>(h->h_ctr[C_BRICKS], h->t.max_bricks);
     return HFPF_OK;
 }

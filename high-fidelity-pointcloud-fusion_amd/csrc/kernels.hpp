@@ -744,7 +744,17 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
             wave_flush_members(t, q, member, d[k], sid[k]);
         }
     }
-    wave_count(&t.ctr[C_REPLAY_MEMBER], replayed);
+    // Diagnostic count of replayed members: reduced per workgroup and striped over the 64 counter lines of log_ctr (word 1 of
+    // each line; the host sums them in read_counters).  One counter bumped once per wave would be ~1e5 same-address atomics
+    // at ~12 ns each in the first pass -- most of this kernel's time.
+    __shared__ unsigned int s_rep;
+    if (threadIdx.x == 0) s_rep = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) replayed += __shfl_down(replayed, o);
+    if ((threadIdx.x & 63u) == 0 && replayed) atomicAdd(&s_rep, replayed);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rep) atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 1], (unsigned long long)s_rep);
 }
 
 // ---- dependant table rebuild --------------------------------------------------------------------
