@@ -197,6 +197,13 @@ int read_counters(hfpf_handle* h)
     unsigned long long replayed = 0;  // striped diagnostic counter of k_replay (word 1 of every log_ctr line)
     for (int r = 0; r < kLogRegions; r++) replayed += h->h_log_ctr[r * 16 + 1];
     h->h_ctr[C_REPLAY_MEMBER] = replayed;
+    unsigned long long upd_tested = 0, upd_member = 0;  // k_update's striped pair counters (words 2, 3); k_integrate's direct path adds to ctr[]
+    for (int r = 0; r < kLogRegions; r++) {
+        upd_tested += h->h_log_ctr[r * 16 + 2];
+        upd_member += h->h_log_ctr[r * 16 + 3];
+    }
+    h->h_ctr[C_DEP_TESTED] += upd_tested;
+    h->h_ctr[C_DEP_MEMBER] += upd_member;
     h->n_bricks_known = std::min<uint64_t>(h->h_ctr[C_BRICKS], h->t.max_bricks);
     return HFPF_OK;
 }

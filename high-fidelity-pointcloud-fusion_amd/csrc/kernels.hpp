@@ -412,8 +412,9 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
         if (c_member) atomicAdd(&blk_ctr[1], c_member);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && blk_ctr[0]) atomicAdd(&t.ctr[C_DEP_TESTED], (unsigned long long)blk_ctr[0]);
-    if (threadIdx.x == 1 && blk_ctr[1]) atomicAdd(&t.ctr[C_DEP_MEMBER], (unsigned long long)blk_ctr[1]);
+    // striped like k_replay's counter: words 2 and 3 of the 64 log_ctr lines, summed by the host
+    if (threadIdx.x < 2 && blk_ctr[threadIdx.x])
+        atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
 }
 
 // Plan the brick regions of the next launch from the demand of the previous one: cap = demand * scale * 1.25 + 64.
