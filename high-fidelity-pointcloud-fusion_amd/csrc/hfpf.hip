@@ -732,35 +732,35 @@ int clean_locked(hfpf_handle* h)
     hipLaunchKernelGGL(k_register, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
     hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand), (int)C_TOUCHED, 0ull, -1, 0ull);
     HIPCHK(h, hipGetLastError());
-    if ((rc = read_counters(h))) return rc;
-    if ((rc = check_device_errors(h))) return rc;
-    const uint64_t n_reg = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
-    const uint64_t n_pre = std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
-    const uint64_t n_chg = std::min<uint64_t>(h->h_ctr[C_PRECHG], t.max_reg);
-    const uint64_t n_new = n_reg - h->reg_done;
-    uint64_t inc_touched = 0;
-    // incremental update; a conservative space estimate decides whether to compact instead
-    bool full = h->h_ctr[C_DEP] + 8 * n_new + n_chg > t.max_dep;
+    // No readback here: the registration counts of this pass are bounded by (2K+1) * n_cand, the kernels below read the exact
+    // counts from the device counters (kCountOnDevice), and the host picks the values up at the readback after them.
+    const uint64_t reg_ub = (2ull * (uint64_t)h->g.K + 1ull) * n_cand;
+    uint64_t n_reg = 0, n_pre = 0, inc_touched = 0;
+    // incremental update; a conservative space estimate decides whether to compact instead (C_DEP as of the last readback:
+    // nothing has changed it since)
+    bool full = h->h_ctr[C_DEP] + 8 * reg_ub + reg_ub > t.max_dep;
     if (!full) {
-        if (n_new) {
-            hipLaunchKernelGGL(k_depinc_count, dim3(blocks_for(n_new, 256 * kListTiles)), dim3(256), 0, s, t, h->reg_done, n_reg);
-            HIPCHK(h, hipGetLastError());
-            if ((rc = read_counters(h))) return rc;
-            const uint64_t n_touched = h->h_ctr[C_TOUCHED];
-            hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(n_touched, 256 * kListTiles)), dim3(256), 0, s, t, n_touched);
-            hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(n_new, 256)), dim3(256), 0, s, t, h->reg_done, n_reg);
-            hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(n_touched, 256)), dim3(256), 0, s, t, n_touched);
-            inc_touched = n_touched;
-        }
-        if (n_chg) hipLaunchKernelGGL(k_depinc_pre, dim3(blocks_for(n_chg, 256 * kListTiles)), dim3(256), 0, s, t, n_chg);
+        hipLaunchKernelGGL(k_depinc_count, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, h->reg_done, kCountOnDevice);
+        hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, kCountOnDevice);
+        hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(reg_ub, 256)), dim3(256), 0, s, t, h->reg_done, kCountOnDevice);
+        hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(reg_ub, 256)), dim3(256), 0, s, t, kCountOnDevice);
+        hipLaunchKernelGGL(k_depinc_pre, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, kCountOnDevice);
         HIPCHK(h, hipGetLastError());
         if ((rc = read_counters(h))) return rc;
+        n_reg = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
+        n_pre = std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
+        inc_touched = h->h_ctr[C_TOUCHED];
         if (h->h_ctr[C_ERR] == (unsigned long long)E_DEP) {  // dep[] ran out mid-way: compact
             hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_ERR, 0ull);
             full = true;
         } else if ((rc = check_device_errors(h))) {
             return rc;
         }
+    } else {
+        if ((rc = read_counters(h))) return rc;
+        if ((rc = check_device_errors(h))) return rc;
+        n_reg = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
+        n_pre = std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
     }
     if (full) {
         const uint64_t n_all = n_reg + n_pre;

@@ -45,6 +45,9 @@ constexpr int kLogRegions = 64;
 #define HFPF_REG_TILES 8  // 256-voxel tiles one workgroup of k_register takes per list reservation
 #endif
 constexpr int kRegTiles = HFPF_REG_TILES;
+// Passed instead of an element count: the kernel reads the exact count from its device counter and the host sizes the grid
+// from an upper bound, which saves a host round trip between two kernels of a clean pass.
+constexpr uint64_t kCountOnDevice = ~0ull;
 constexpr int kListTiles = 4;  // same idea for the k_depinc_* list builders (not k_gate: it is latency-heavy per cell and needs every workgroup it can get)
 typedef float vf4 __attribute__((ext_vector_type(4)));  // native vector type (the nontemporal builtins do not take HIP's float4)
 
@@ -814,8 +817,9 @@ __global__ __launch_bounds__(256) void k_dep_fill(const Tables t, const uint64_t
 
 __global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_t n_touched)
 {
+    const uint64_t n = n_touched == kCountOnDevice ? (uint64_t)t.ctr[C_TOUCHED] : n_touched;
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n_touched) t.dep_tmp[t.touched_list[j]] = 0;
+    if (j < n) t.dep_tmp[t.touched_list[j]] = 0;
 }
 
 
@@ -839,8 +843,9 @@ __device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid
     return e;
 }
 
-__global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg)
+__global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg)
 {
+    const uint64_t n_reg = n_reg_arg == kCountOnDevice ? min((uint64_t)t.ctr[C_REG], t.max_reg) : n_reg_arg;
     uint32_t slot_[kListTiles];
     uint32_t f_fresh = 0;
 #pragma unroll
@@ -863,8 +868,9 @@ __global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint
         if (n_f[tt]) t.touched_list[ti[tt]] = slot_[tt];
 }
 
-__global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched)
+__global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched_arg)
 {
+    const uint64_t n_touched = n_touched_arg == kCountOnDevice ? (uint64_t)t.ctr[C_TOUCHED] : n_touched_arg;
     uint32_t slot_[kListTiles], old_cnt_[kListTiles], new_cnt_[kListTiles];
     uint64_t info_[kListTiles];
 #pragma unroll
@@ -903,8 +909,9 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
     }
 }
 
-__global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint64_t reg_first, const uint64_t n_reg)
+__global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg)
 {
+    const uint64_t n_reg = n_reg_arg == kCountOnDevice ? min((uint64_t)t.ctr[C_REG], t.max_reg) : n_reg_arg;
     const uint64_t j = reg_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_reg) return;
     const uint2 r = t.reg_occ[j];
@@ -915,8 +922,9 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
 }
 
 // Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).
-__global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64_t n_chg)
+__global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64_t n_chg_arg)
 {
+    const uint64_t n_chg = n_chg_arg == kCountOnDevice ? min((uint64_t)t.ctr[C_PRECHG], t.max_reg) : n_chg_arg;
     uint32_t slot_[kListTiles];
     uint64_t info_[kListTiles];
     uint32_t f_fresh = 0;
