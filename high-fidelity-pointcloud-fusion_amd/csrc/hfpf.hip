@@ -671,6 +671,16 @@ int dist_exchange_locked(hfpf_handle* h)
     return HFPF_OK;
 }
 
+// k_gate with four tiles per workgroup only when the input is large enough to fill the chip that way (one reservation per
+// list and workgroup; small inputs keep one tile so that the latency-heavy stencil probes spread over as many CUs as possible).
+void launch_gate(hfpf_handle* h, const uint32_t* cells, uint64_t n, uint32_t* pend_out)
+{
+    if (n >= (1ull << 20))
+        hipLaunchKernelGGL(k_gate<4>, dim3(blocks_for(n, 256 * 4)), dim3(256), 0, h->stream, h->g, h->t, cells, n, pend_out);
+    else
+        hipLaunchKernelGGL(k_gate<1>, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, h->t, cells, n, pend_out);
+}
+
 int clean_locked(hfpf_handle* h)
 {
     Tables& t = h->t;
@@ -708,10 +718,9 @@ int clean_locked(hfpf_handle* h)
     if ((rc = scratch(h, h->pend_b, std::max<uint64_t>(h->n_pend + n_new_occ, 1) * 4))) return rc;
     hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull, (int)C_PEND, 0ull, (int)C_PRECHG, 0ull);
     if (h->n_pend)
-        hipLaunchKernelGGL(k_gate, dim3(blocks_for(h->n_pend, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->pend_a.p, h->n_pend, (uint32_t*)h->pend_b.p);
+        launch_gate(h, (const uint32_t*)h->pend_a.p, h->n_pend, (uint32_t*)h->pend_b.p);
     if (n_new_occ)
-        hipLaunchKernelGGL(k_gate, dim3(blocks_for(n_new_occ, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ,
-                           (uint32_t*)h->pend_b.p);
+        launch_gate(h, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, (uint32_t*)h->pend_b.p);
     HIPCHK(h, hipGetLastError());
     h->gate_done = n_occ;
     if ((rc = read_counters(h))) return rc;

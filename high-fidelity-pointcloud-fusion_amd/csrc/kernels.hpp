@@ -493,31 +493,45 @@ __device__ inline void neighbourhood(const GridParams& g, const Tables& t, int32
 
 // K3: every occupied cell without a normal is a candidate (the reference's unprocessed_data_ set is
 // a superset whose extra members fail the same gate, grid.hpp:315,352).
+template <int TILES>
 __global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint64_t n_cells,
                                               uint32_t* __restrict__ pend_out)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pass = false, pend = false;
-    uint64_t key = 0;
-    uint32_t slot = 0;
-    if (j < n_cells) {
-        slot = cells[j];
-        if (!(t.info[slot] & kNormal)) {
-            int32_t x, y, z;
-            slot_coords(g, t, slot, x, y, z);
-            uint64_t lo, hi;
-            neighbourhood(g, t, x, y, z, lo, hi);
-            const int total = __popcll(lo) + __popcll(hi);
-            pass = total > g.gate;
-            pend = !pass;  // still without a normal: look at it again next pass (its neighbourhood may fill up)
-            key = make_key(x, y, z);
+    // TILES tiles per workgroup, one reservation per output list (hot list counters: see k_register).  The host uses
+    // TILES = 4 only for large inputs: the stencil probe is latency-heavy and a small grid needs every workgroup it can get.
+    uint64_t key_[TILES];
+    uint32_t slot_[TILES];
+    uint32_t n_pass[TILES], n_pend[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * TILES + tt) * 256u + threadIdx.x;
+        key_[tt] = 0;
+        slot_[tt] = 0;
+        n_pass[tt] = n_pend[tt] = 0;
+        if (j < n_cells) {
+            const uint32_t slot = cells[j];
+            slot_[tt] = slot;
+            if (!(t.info[slot] & kNormal)) {
+                int32_t x, y, z;
+                slot_coords(g, t, slot, x, y, z);
+                uint64_t lo, hi;
+                neighbourhood(g, t, x, y, z, lo, hi);
+                const int total = __popcll(lo) + __popcll(hi);
+                if (total > g.gate) n_pass[tt] = 1;
+                else n_pend[tt] = 1;  // still without a normal: look at it again next pass (its neighbourhood may fill up)
+                key_[tt] = make_key(x, y, z);
+            }
         }
     }
-    __shared__ BlockReserveScratch brs;
-    const unsigned long long ci = block_reserve(&t.ctr[C_CAND], pass, brs);
-    if (pass) t.cand_key[ci] = key;  // capacity = max_occ >= cells examined
-    const unsigned long long pi = block_reserve(&t.ctr[C_PEND], pend, brs);
-    if (pend) pend_out[pi] = slot;
+    __shared__ TileReserveScratch<TILES> trs;
+    unsigned long long ci[TILES], pi[TILES];
+    block_reserve_tiles<TILES>(&t.ctr[C_CAND], n_pass, ci, trs);
+    block_reserve_tiles<TILES>(&t.ctr[C_PEND], n_pend, pi, trs);
+#pragma unroll
+    for (int tt = 0; tt < TILES; tt++) {
+        if (n_pass[tt]) t.cand_key[ci[tt]] = key_[tt];  // capacity = max_occ >= cells examined
+        if (n_pend[tt]) pend_out[pi[tt]] = slot_[tt];
+    }
 }
 
 // K4: one thread per candidate, in ascending key order; record id = base + rank + 1.
