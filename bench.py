@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mpts/s fused into a 1 mm voxel grid (BASELINE.json).
 
-A "step" is one 640x480 synthetic organised XYZRGB frame (307,200 points, published height=1) pushed
-through the hot path: decode + z-clip + SE(3) + bbox clip + voxel insert/append + dependant updates, with a
-clean pass every --clean-every frames and a final clean, all inside the timed region.  Frames are
-pre-staged in HBM before the clock starts (configs[1] of BASELINE.json: 1000-frame stream, random SE(3)
-poses, 1 m^3 bbox @ 1 mm on one MI355X).  Extract is timed separately and reported as `extract_s`.
-
     python bench.py --gpus N --steps K --warmup W
 
-For N>1 the driver launches one rank per GPU with torch.distributed.run; every rank fuses its own K-frame
-camera stream (weak scaling) and the engine merges occupancy / statistics over RCCL.
+A "step" is one 50-frame slice of the synthetic 640x480 organised XYZRGB stream (15,360,000 points, published
+height=1) pushed through the hot path: decode + z-clip + SE(3) + bbox clip + voxel insert/append + dependant updates.
+The stream is handed to the engine one clean epoch at a time (3 steps = 150 frames per hfpf_integrate_device call),
+with a clean pass after every epoch and a final clean, all inside the timed region -- the cadence of the reference's
+cleanGrid thread (sleep(5) at ~30 Hz, node.cpp:323).  The default K = 20 steps is therefore exactly configs[1] of
+BASELINE.json: the 1000-frame stream with random SE(3) poses into a 1 m^3 bbox @ 1 mm on one MI355X, 7 clean passes.
+W warm-up steps run the same schedule untimed; the grid is cleared before every timed pass.
+
+Timing protocol: frames are pre-staged in HBM before the clock starts; the K-step stream is timed
+--repeats times (clear between), each pass bracketed by barrier + device sync, max over ranks; `value` is the MEDIAN
+pass, min/max are reported beside it.  Extract is timed separately (`extract_s`), so is the host-buffer entry point
+(`host_path_mpts`, PCIe inclusive, never `value`).
+
+For N>1 the driver launches one rank per GPU with torch.distributed.run; every rank fuses its own camera stream into
+the shared grid (weak scaling) and the engine merges occupancy / statistics over RCCL.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,27 +39,42 @@ import hfpf_synth as S  # noqa: E402
 POINT_STEP = 16
 # BASELINE.json configs the bench can run on one GPU (or one stream per GPU).  The default is configs[1], the
 # configuration the metric is quoted on; the others are selectable for documentation runs, never the driver's line.
+# frames_per_step x default --steps = the frame count BASELINE.json names for the config.
 WORKLOADS = {
-    "c1": dict(name="configs[1]", W=640, H=480, bbox=(-0.5, 0.5, -0.5, 0.5, 0.0, 1.0), res=0.001, steps=1000,
+    "c1": dict(name="configs[1]", W=640, H=480, bbox=(-0.5, 0.5, -0.5, 0.5, 0.0, 1.0), res=0.001, frames_per_step=50, steps=20,
                desc="%d-frame synthetic 640x480 stream, random SE(3) poses, 1 m^3 bbox @ 1 mm"),
-    "c3": dict(name="configs[2]", W=2048, H=1536, bbox=(-1.0, 1.0, -0.5, 0.5, 0.0, 1.0), res=0.0005, steps=100,
+    "c3": dict(name="configs[2]", W=2048, H=1536, bbox=(-1.0, 1.0, -0.5, 0.5, 0.0, 1.0), res=0.0005, frames_per_step=5, steps=20,
                desc="%d-frame synthetic 2048x1536 stream, random SE(3) poses, 2 m^3 bbox @ 0.5 mm"),
-    "c5": dict(name="configs[4] grid", W=640, H=480, bbox=(-1.25, 1.25, -1.0, 1.0, 0.0, 2.0), res=0.001, steps=1000,
+    "c4": dict(name="configs[3]", W=640, H=480, bbox=(-1.0, 1.0, -0.5, 0.5, 0.0, 1.0), res=0.001, frames_per_step=50, steps=20,
+               desc="%d-frame synthetic 640x480 stream per camera (one camera per GPU, distinct pose seeds), shared 2 m^3 bbox @ 1 mm (1999x999x999 cells)"),
+    "c5": dict(name="configs[4] grid", W=640, H=480, bbox=(-1.25, 1.25, -1.0, 1.0, 0.0, 2.0), res=0.001, frames_per_step=50, steps=20,
                desc="%d-frame synthetic 640x480 stream, random SE(3) poses, 10 m^3 bbox @ 1 mm (2499x1999x1999 cells)"),
 }
 W = H = NPTS = 0
 BBOX = RES = None
 ALGO_BYTES_PER_POINT = 32  # 16 B point read + 16 B voxel-record touch
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_GBPS = 6290.0  # MI355X_MICROARCH.md: float4 copy
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_hot_path.json")
+KERNEL_SOURCES = ("kernels.hpp", "tables.hpp", "stats.hpp", "geometry.hpp", "det_math.hpp", "hfpf.hip")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_stream(seed, pose_seed, n_frames):
-    poses = np.stack([S.pose(pose_seed, f, 30.0, 0.05) for f in range(n_frames)]).reshape(n_frames, 12)
-    return poses
+def kernel_source_sha():
+    """Identity of the kernels this run executes: hash of the csrc sources libhfpf.so is built from.  The PMC summary under
+    profiles/ records the same hash, so stale counters are never attached to a newer build."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(PKG, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def make_stream(pose_seed, n_frames):
+    return np.stack([S.pose(pose_seed, f, 30.0, 0.05) for f in range(n_frames)]).reshape(n_frames, 12)
 
 
 def cpu_baseline(poses, seed, n_sample, all_cores=False):
@@ -83,11 +107,6 @@ def cpu_baseline(poses, seed, n_sample, all_cores=False):
                       "restatement without the reference's 24 kB reserve per voxel (%.1f s)" % (n_sample, half, how, dt)}
 
 
-def call_frames(args):
-    """Frames handed to one hfpf_integrate_device call."""
-    return max(1, min(args.frames_per_call, int(os.environ.get("HFPF_BENCH_CALL_POINTS", 150 * 307200)) // NPTS))
-
-
 def claim_stdout():
     """The contract is ONE JSON line on stdout.  Gloo and RCCL print banners on file descriptor 1 from C code, so keep a private
     handle to the real stdout for that line and point fd 1 (and Python's sys.stdout) at stderr for everything else."""
@@ -98,25 +117,48 @@ def claim_stdout():
     return real
 
 
+def load_pmc(src_sha):
+    """Measured HBM-side traffic of the integrate hot path from the committed `rocprofv3 --pmc` passes (PMC counters cannot
+    be read inside this process).  Returns (dict or None, reason): refuses counters taken on different kernel sources."""
+    if not os.path.exists(PMC_JSON):
+        return None, "no %s (collect with tools/collect_profiles.sh + tools/pmc_summary.py)" % os.path.relpath(PMC_JSON, ROOT)
+    with open(PMC_JSON) as f:
+        pmc = json.load(f)
+    if pmc.get("source_sha") != src_sha:
+        return None, "%s was collected on kernel sources %s, this build is %s: not measured for this build" % (
+            os.path.relpath(PMC_JSON, ROOT), pmc.get("source_sha"), src_sha)
+    return pmc, "%s (FETCH_SIZE with the gfx950 wide-read correction + WRITE_SIZE of the integrate kernels, separate --pmc passes on this build)" % os.path.relpath(PMC_JSON, ROOT)
+
+
 def main():
     json_out = claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1")
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--clean-every", type=int, default=150)
-    ap.add_argument("--frames-per-call", type=int, default=150, help="frames handed to one hfpf_integrate_device call (one clean epoch by default)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps; one step = --frames-per-step frames (default 20 = the config's whole stream)")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps")
+    ap.add_argument("--frames-per-step", type=int, default=None, help="frames in one step (default 50 for 640x480 streams)")
+    ap.add_argument("--clean-every-steps", type=int, default=3, help="clean pass every this many steps (3 x 50 frames = 150 frames ~ 5 s at 30 Hz) + final clean")
+    ap.add_argument("--repeats", type=int, default=5, help="timed passes over the K-step stream (median reported)")
+    ap.add_argument("--frames-per-call", type=int, default=0, help="frames handed to one hfpf_integrate_device call (0 = one clean epoch)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--write-dir", default=None, help="also time writing test_cloud.pcd (ASCII + binary) and meta.csv there")
-    ap.add_argument("--host-path-frames", type=int, default=20, help="frames also pushed through the host-buffer entry point")
+    ap.add_argument("--host-path-frames", type=int, default=200, help="frames also pushed through the host-buffer entry point (0 = skip)")
+    ap.add_argument("--allow-host-staged", action="store_true", help="rehearsals with several ranks on ONE GPU: fall back to the gloo host-staged transport when RCCL cannot form a communicator")
     args = ap.parse_args()
     global W, H, NPTS, BBOX, RES
     wl = WORKLOADS[args.workload]
     W, H, BBOX, RES = wl["W"], wl["H"], wl["bbox"], wl["res"]
     NPTS = W * H
-    if args.steps is None:
-        args.steps = wl["steps"]
+    K = args.steps if args.steps is not None else wl["steps"]
+    Wm = max(0, args.warmup)
+    fps = args.frames_per_step or wl["frames_per_step"]
+    if K < 1 or fps < 1 or args.repeats < 1:
+        raise SystemExit("--steps, --frames-per-step and --repeats must be >= 1")
+    n_frames = K * fps
+    clean_every = args.clean_every_steps * fps  # frames
+    call_frames = args.frames_per_call if args.frames_per_call > 0 else (clean_every if clean_every else n_frames)
+    call_frames = max(1, min(call_frames, n_frames, int(os.environ.get("HFPF_BENCH_CALL_POINTS", 1 << 31)) // NPTS))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -128,33 +170,36 @@ def main():
         import torch.distributed as dist  # rank bootstrap + barriers only; the data path is the engine's own RCCL
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    K, Wm = args.steps, args.warmup
     seed = 0xF051 + 7919 * rank  # one camera stream per GPU (BASELINE configs[3] style sharding)
     pose_seed = 0x5E3 + 104729 * rank
-    n_gen = max(K, Wm)
-    poses = make_stream(seed, pose_seed, n_gen)
+    n_gen = max(n_frames, Wm * fps)
+    poses = make_stream(pose_seed, n_gen)
 
-    device = local_rank
+    device, n_dev = local_rank, 1
     if world > 1:
         import torch
         n_dev = torch.cuda.device_count()  # does not initialise the GPU
         if n_dev > 0:
-            device = local_rank % n_dev  # rehearsals with more ranks than GPUs share devices (RCCL then falls back)
+            device = local_rank % n_dev  # rehearsals with more ranks than GPUs share devices
     grid = hfpf.OccupancyGrid(resolution=RES, bbox=BBOX, device=device, max_bricks=400000,
                               max_log_points=min(max(n_gen, 64) * NPTS, 1 << 31), max_normals=24 << 20,
                               max_frames=max(n_gen * max(world, 1) + 16, 4096),
                               frame_width=int(os.environ.get("HFPF_FRAME_WIDTH", W)),  # organised W x H frames: 16x16-pixel tiles
-                              max_call_points=call_frames(args) * NPTS)  # per-call bins sized at create, like the other pools
+                              max_call_points=call_frames * NPTS)  # per-call bins sized at create, like the other pools
     transport = "none"
     if world > 1:
         import hfpf_dist
         ok, why = hfpf_dist.init_rccl(grid, dist, hfpf)  # data path = the engine's own RCCL collectives over xGMI
         if ok:
-            transport = "rccl"
-        else:  # keep measuring: stage the same exchange through the launcher's process group (all ranks agree)
-            log("rank %d: RCCL bootstrap failed (%s); falling back to the host-staged transport" % (rank, why))
+            transport = "rccl, %d ranks" % grid.dist_world()
+        elif args.allow_host_staged or world > n_dev:
+            # several ranks share a GPU (a rehearsal on a 1-GPU box): RCCL cannot put two ranks on one device
+            log("rank %d: RCCL bootstrap failed (%s); ranks share a device, using the host-staged transport" % (rank, why))
             grid.attach_transport(hfpf_dist.HostStagedTransport(dist))
-            transport = "host-staged (gloo)"
+            transport = "host-staged (gloo), %d ranks" % world
+        else:  # one GPU per rank and still no communicator: a scaling number over gloo would be meaningless
+            log("rank %d: RCCL bootstrap failed (%s) with %d ranks on %d devices: refusing to benchmark the fallback transport" % (rank, why, world, n_dev))
+            sys.exit(3)
 
     # ---- stage frames in HBM (not timed) ----
     t_gen = time.perf_counter()
@@ -162,76 +207,65 @@ def main():
     dev = grid.device_alloc(n_gen * frame_bytes)
     buf = np.empty(frame_bytes, dtype=np.uint8)
     host_frames = []
-    t_synth = t_up = 0.0
+    n_host = min(args.host_path_frames, n_gen) if (rank == 0 and world == 1) else 0
     for f in range(n_gen):
-        ta = time.perf_counter()
         S.frame(seed, f, W, H, poses[f].reshape(3, 4), out=buf)
-        tb = time.perf_counter()
         grid.device_upload(dev + f * frame_bytes, buf)
-        t_synth += tb - ta
-        t_up += time.perf_counter() - tb
-        if f < args.host_path_frames:
+        if f < n_host:
             host_frames.append(buf.copy())
-    log("rank %d: staged %d frames (%.2f GB) in %.1f s (synth %.1f s, upload %.1f s, %d cpus)" % (
-        rank, n_gen, n_gen * frame_bytes / 1e9, time.perf_counter() - t_gen, t_synth, t_up, os.cpu_count()))
+    log("rank %d: staged %d frames (%.2f GB) in %.1f s" % (rank, n_gen, n_gen * frame_bytes / 1e9, time.perf_counter() - t_gen))
 
-    clean_time = [0.0]
-
-    def timed_clean():
-        tc = time.perf_counter()
-        grid.clean()  # synchronises (reads device counters)
-        clean_time[0] += time.perf_counter() - tc
-
-    def run_stream(n_frames, timed):
+    def run_stream(nf):
+        """nf frames: one integrate call per clean epoch (or --frames-per-call), clean after every epoch, final clean."""
         done = 0
-        B = call_frames(args)
-        while done < n_frames:
-            nxt = n_frames
-            if args.clean_every:
-                nxt = min(nxt, (done // args.clean_every + 1) * args.clean_every)
-            b = min(B, nxt - done)
+        while done < nf:
+            nxt = nf
+            if clean_every:
+                nxt = min(nxt, (done // clean_every + 1) * clean_every)
+            b = min(call_frames, nxt - done)
             ids = ((np.arange(done, done + b, dtype=np.int64) * world) + rank).astype(np.uint32)  # global frame ids
             grid.integrate_device(dev + done * frame_bytes, b, frame_bytes, NPTS, poses[done:done + b], frame_ids=ids)
             done += b
-            if args.clean_every and done % args.clean_every == 0 and done < n_frames:
-                timed_clean()
-        timed_clean()
+            if clean_every and done % clean_every == 0 and done < nf:
+                grid.clean()  # synchronises (reads device counters)
+        grid.clean()
 
-    # ---- warmup (untimed), then reset ----
+    # ---- warmup (untimed) ----
     if Wm > 0:
-        run_stream(Wm, False)
+        run_stream(Wm * fps)
         grid.sync()
-    grid.clear()
-    grid.sync()
 
-    # ---- timed region: exactly K steps ----
+    # ---- timed region: exactly K steps per pass, `repeats` passes ----
     grid.kernel_timing(True)
-    if dist is not None:
-        dist.barrier()
-    grid.sync()
-    clean_time[0] = 0.0
-    t0 = time.perf_counter()
-    run_stream(K, True)
-    grid.sync()
-    t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed_all = []
+    for rep in range(args.repeats):
+        grid.clear()
+        grid.sync()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        run_stream(n_frames)
+        grid.sync()
+        t1 = time.perf_counter()
+        if dist is not None:
+            dist.barrier()
+        e = t1 - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([e], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt.item())
+        elapsed_all.append(e)
+    elapsed = statistics.median(elapsed_all)
     k_ms, k_launches = grid.kernel_time(0)
     clean_ms, clean_passes = grid.kernel_time(1)
     grid.kernel_timing(False)
-    ctr = grid.counters()
+    ctr = grid.counters()  # of the last pass (the grid is cleared between passes)
 
     # ---- extract (timed separately) ----
     t2 = time.perf_counter()
     rows = grid.extract()
-    t3 = time.perf_counter()
-    extract_s = t3 - t2
+    extract_s = time.perf_counter() - t2
     write_times = None
     if rank == 0 and args.write_dir:
         os.makedirs(args.write_dir, exist_ok=True)
@@ -246,7 +280,7 @@ def main():
 
     # ---- host-buffer entry point (PCIe-inclusive), informational ----
     host_mpts = None
-    if rank == 0 and world == 1 and host_frames:
+    if host_frames:
         grid.clear()
         grid.sync()
         th = time.perf_counter()
@@ -255,26 +289,28 @@ def main():
         grid.sync()
         host_mpts = len(host_frames) * NPTS / (time.perf_counter() - th) / 1e6
 
-    total_pts = K * NPTS * world
+    total_pts = n_frames * NPTS * world
     value = total_pts / elapsed / 1e6
     if rank == 0:
-        pts_per_launch = (K * NPTS) / max(k_launches, 1)
+        R = args.repeats
+        warnings = []
+        pts_per_launch = (R * n_frames * NPTS) / max(k_launches, 1)
         avg_launch_s = (k_ms / 1e3) / max(k_launches, 1)
         achieved = ALGO_BYTES_PER_POINT * pts_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # HBM-side traffic of k_integrate: PMC counters cannot be read live, so the per-point figures measured by
-        # separate `rocprofv3 --pmc` passes on this same workload (profiles/r01_pmc_k_integrate.*) are scaled to this run.
-        traffic, traffic_src, atomic_req = None, None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hot_path.json")))
-            n_first = min(k_launches, (args.clean_every // max(1, args.frames_per_call)) if args.clean_every else 0)
-            bpp = (n_first * pmc["first_epoch_buffer_only"]["traffic_bytes_per_point"] +
-                   (k_launches - n_first) * pmc["steady_state_after_first_clean"]["traffic_bytes_per_point"]) / max(k_launches, 1)
+        src_sha = kernel_source_sha()
+        pmc, traffic_src = load_pmc(src_sha)
+        traffic = atomic_req = None
+        if pmc is not None:
+            launches_per_pass = k_launches / R
+            n_first = min(launches_per_pass, max(1, clean_every // call_frames) if clean_every else launches_per_pass)
+            w_first = n_first / launches_per_pass
+            bpp = (w_first * pmc["first_epoch_buffer_only"]["traffic_bytes_per_point"] +
+                   (1 - w_first) * pmc["steady_state_after_first_clean"]["traffic_bytes_per_point"])
             traffic = round(bpp * pts_per_launch)
-            traffic_src = "profiles/r01_pmc_hot_path.json (FETCH_SIZE corrected + WRITE_SIZE of k_integrate + k_update, separate --pmc passes), scaled by points per launch"
-            atomic_req = (n_first * pmc["first_epoch_buffer_only"]["atomic_requests"] +
-                          (k_launches - n_first) * pmc["steady_state_after_first_clean"]["atomic_requests"]) / max(k_launches, 1) * (pts_per_launch / pmc["points_per_launch"])
-        except Exception:
-            pass
+            atomic_req = (w_first * pmc["first_epoch_buffer_only"]["atomic_requests"] +
+                          (1 - w_first) * pmc["steady_state_after_first_clean"]["atomic_requests"]) * (pts_per_launch / pmc["points_per_launch"])
+        if ctr["dep_pairs_tested"] == 0:
+            warnings.append("dep_pairs_tested == 0: the stream never reached the steady state (no dependant updates ran); not the headline configuration")
         out = {
             "metric": "Mpts/s fused into 1 mm voxel grid" if RES == 0.001 else "Mpts/s fused into %g mm voxel grid" % (RES * 1e3),
             "value": round(value, 3),
@@ -285,28 +321,36 @@ def main():
             "ms_per_step": round(elapsed * 1e3 / K, 5),
             "higher_is_better": True,
             "scaling": "weak",
-            "vs_baseline": None,
+            "vs_baseline": None,  # BASELINE.md holds no published number for this metric
             "dtype": "f64",
             "dtype_detail": "f64 SE(3) transform and voxel index, f32 projection/plane-fit geometry, int64 fixed-point statistic sums",
             "data": "synthetic",
-            "config": {"workload": "%s: %s, clean every %d frames + final clean" % (wl["name"], wl["desc"] % K, args.clean_every),
-                       "points_per_step": NPTS, "frames_per_call": args.frames_per_call, "parallelism": "one camera stream per GPU, %d rank(s), transport %s" % (world, transport)},
+            "config": {"workload": "%s: %s; %d steps of %d frames, one integrate call per %d frames, clean every %d frames + final clean" % (
+                           wl["name"], wl["desc"] % n_frames, K, fps, call_frames, clean_every),
+                       "points_per_step": fps * NPTS, "frames_per_step": fps, "frames_per_call": call_frames, "frames": n_frames,
+                       "parallelism": "one camera stream per GPU, %d rank(s), transport %s" % (world, transport)},
+            "repeats": R,
+            "value_min": round(total_pts / max(elapsed_all) / 1e6, 3),
+            "value_max": round(total_pts / min(elapsed_all) / 1e6, 3),
+            "pass_s": [round(e, 6) for e in elapsed_all],
             "extract_s": round(extract_s, 5),
-            "clean_s": round(clean_ms / 1e3, 5),  # HIP-event time of the clean passes alone (inside the timed region)
-            "clean_passes": int(clean_passes),
+            "clean_s": round(clean_ms / 1e3 / R, 5),  # HIP-event time of the clean passes of ONE timed pass (inside the timed region)
+            "clean_passes": int(round(clean_passes / R)),
             "rows_extracted": int(len(rows)),
             "write_times": write_times,
-            "integrate_kernel_mpts": round(K * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,
+            "integrate_kernel_mpts": round(R * n_frames * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,
             "host_path_mpts": round(host_mpts, 3) if host_mpts else None,
+            "host_path_frames": len(host_frames),
             "counters": {k: int(v) for k, v in ctr.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_integrate + k_update (one hfpf_integrate_device call incl. the bin plan)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT, "launches": int(k_launches),
+            "warnings": warnings,
+            "roofline": {"bound": "hbm", "kernel": "the integrate call (bin plan + k_integrate + k_update), HIP events on the engine's stream around every call of the timed passes",
+                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBPS, 6),
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_source_sha": src_sha,
+                         "algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT, "points_per_launch": round(pts_per_launch), "launches": int(k_launches),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5),
-                         # the ceiling that actually binds k_integrate: one 64-byte memory-side atomic
-                         # request per (point, dependant) pair; chip-wide rate 1.3 TB/s / 64 B (MI355X_MICROARCH.md)
-                         # the ceiling that bound the one-atomic-per-pair form: chip-wide 1.3 TB/s / 64 B requests;
-                         # request counts from the committed PMC passes, scaled to this run
+                         # secondary ceiling: memory-side atomic requests, chip-wide 1.3 TB/s / 64 B (MI355X_MICROARCH.md);
+                         # request counts from the same PMC passes, null when those are not of this build
                          "secondary": {"bound": "memory-side atomic requests", "unit": "Greq/s",
                                        "achieved": round(atomic_req / avg_launch_s / 1e9, 3) if atomic_req and avg_launch_s > 0 else None,
                                        "peak": round(1300.0 / 64.0, 3),
@@ -315,6 +359,7 @@ def main():
         if args.cpu_sample > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen))
             out["cpu_baseline_all_cores"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen), all_cores=True)
+            out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)  # informational; vs_baseline stays null (no published number)
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     grid.device_free(dev)

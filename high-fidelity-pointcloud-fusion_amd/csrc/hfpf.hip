@@ -80,6 +80,7 @@ struct hfpf_handle {
     uint64_t n_linked[kLogRegions] = {0};  // per log region: entries already chained
     unsigned long long* h_log_ctr = nullptr;  // pinned mirror of the region counters
     int integrate_grid = 1536;
+    uint32_t launch_seq = 0;  // integrate launches so far (rotates the log append regions)
     uint64_t frames_integrated = 0;
     uint64_t reg_done = 0;  // reg_occ entries already present in dep[]
     uint64_t gate_done = 0; // occ_list entries already examined by a gate pass
@@ -498,9 +499,10 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
             HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, (h->t.max_bricks + 2) * 4, h->stream));  // no plan yet: every lane goes direct, demand is recorded
         }
     }
+    const uint32_t log_rot = (uint32_t)((h->launch_seq++ * 17u) & (kLogRegions - 1));
 #define HFPF_LAUNCH_INTEGRATE(P, C, B)                                                                                                              \
     hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay, \
-                       (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w)
+                       (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w, log_rot)
     if (!bin) {
         if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, false);
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, false);
@@ -568,6 +570,8 @@ struct RcclApi {
     int (*GetUniqueId)(ncclUniqueId_*) = nullptr;
     int (*CommInitRank)(ncclComm_t_*, int, ncclUniqueId_, int) = nullptr;
     int (*CommDestroy)(ncclComm_t_) = nullptr;
+    int (*CommCount)(const ncclComm_t_, int*) = nullptr;
+    int (*CommUserRank)(const ncclComm_t_, int*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -593,6 +597,8 @@ int load_rccl(std::string& err)
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(lib, "ncclCommUserRank");
     a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
@@ -774,6 +780,9 @@ int clean_locked(hfpf_handle* h)
     if (full) {
         const uint64_t n_all = n_reg + n_pre;
         if (n_all > t.max_dep) return fail(h, HFPF_ERR_CAPACITY, "dependant table: %llu entries > %llu", (unsigned long long)n_all, (unsigned long long)t.max_dep);
+        // touched_list holds one entry per distinct cell among the n_all registrations: every normal record registers on at most
+        // 2K+1 cells, so n_reg + n_pre <= max_normals * (2K+1) = max_reg = max_touched
+        if (n_all > h->max_touched) return fail(h, HFPF_ERR_CAPACITY, "registrations: %llu > %llu", (unsigned long long)n_all, (unsigned long long)h->max_touched);
         hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_DEP, 0ull, (int)C_TOUCHED, 0ull, -1, 0ull);
         if (n_all) {
             hipLaunchKernelGGL(k_dep_count, dim3(blocks_for(n_all, 256)), dim3(256), 0, s, t, n_reg, n_pre);
@@ -1175,6 +1184,21 @@ int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128)
             return rc;
     }
     h->dist_on = true;
+    return HFPF_OK;
+}
+
+int hfpf_dist_info(hfpf_handle* h, int32_t* rank, int32_t* world)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    int r = 0, w = 1;
+    if (h->dist_on && h->comm) {  // what the communicator itself reports, not what the caller passed to hfpf_dist_init
+        if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(h, HFPF_ERR_DIST, "librccl lacks ncclCommCount / ncclCommUserRank");
+        NCCLCHK(h, g_rccl.CommCount((ncclComm_t_)h->comm, &w));
+        NCCLCHK(h, g_rccl.CommUserRank((ncclComm_t_)h->comm, &r));
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
     return HFPF_OK;
 }
 

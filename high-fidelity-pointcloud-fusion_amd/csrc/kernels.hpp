@@ -101,46 +101,51 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kOccStage = 1024;  // newly occupied cells a workgroup of k_integrate stages before appending them to occ_list
-// Append the staged slots with ONE atomic on C_OCC.  Convergent: every thread of the workgroup calls it (contains barriers).
-__device__ __forceinline__ void flush_occ_stage(const Tables& t, uint32_t* s_occ, unsigned int& s_occ_n, unsigned long long& s_base)
+constexpr int kOccStage = 256;  // newly occupied cells ONE WAVE of k_integrate stages before appending them to occ_list
+// Append the wave's staged slots with ONE atomic on C_OCC.  Wave-level only (no workgroup barrier, so waves never have to agree on
+// when to flush); `n` is wave-uniform.  Convergent for the wave.
+__device__ __forceinline__ void flush_occ_stage(const Tables& t, const uint32_t* s_occ, uint32_t n)
 {
-    const uint32_t n = s_occ_n;
-    if (threadIdx.x == 0) s_base = atomicAdd(&t.ctr[C_OCC], (unsigned long long)n);
-    __syncthreads();
+    const uint32_t lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&t.ctr[C_OCC], (unsigned long long)n);
+    base = __shfl(base, 0);
+    // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     bool overflow = false;
-    for (uint32_t k = threadIdx.x; k < n; k += 256) {
-        const unsigned long long oi = s_base + k;
+    for (uint32_t k = lane; k < n; k += 64) {
+        const unsigned long long oi = base + k;
         if (oi < t.max_occ) t.occ_list[oi] = s_occ[k];
         else overflow = true;
     }
     if (overflow) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OCC);
-    __syncthreads();
-    if (threadIdx.x == 0) s_occ_n = 0;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <bool PACKED16, bool COLOR, bool BIN>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
-                                                   const uint32_t* __restrict__ frame_ids, const uint32_t row_w)
+                                                   const uint32_t* __restrict__ frame_ids, const uint32_t row_w, const uint32_t log_rot)
 {
     __shared__ unsigned long long queue[4][64 * kQueueStride];
     __shared__ unsigned int blk_ctr[6];
-    __shared__ uint32_t s_occ[kOccStage];
-    __shared__ unsigned int s_occ_n;
-    __shared__ unsigned long long s_occ_base;
+    __shared__ uint32_t s_occ_all[4][kOccStage];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     unsigned long long* q = queue[wave];
+    uint32_t* s_occ = s_occ_all[wave];
+    uint32_t occ_n = 0;  // wave-uniform: slots staged by this wave
     if (threadIdx.x < 6) blk_ctr[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_occ_n = 0;
     __syncthreads();
 
     const uint32_t tiles_per_frame = (n_pts + 255u) >> 8;
     const uint64_t n_tiles = (uint64_t)tiles_per_frame * n_frames;
-    const uint32_t region = blockIdx.x & (kLogRegions - 1);
+    // log_rot changes from launch to launch, so that launches with fewer than kLogRegions workgroups (small frames through
+    // hfpf_integrate, one frame per call) still fill every append region of the log
+    const uint32_t region = (blockIdx.x + log_rot) & (kLogRegions - 1);
     unsigned long long* log_ctr = &t.log_ctr[region * 16];
     const uint64_t log_base = (uint64_t)region * t.log_region_cap;
     uint32_t c_present = 0, c_z = 0, c_in = 0, c_buf = 0, c_tested = 0, c_member = 0;
@@ -209,11 +214,20 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             if (first) atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (ix & 7)]),
                                 1ull << (((iy & 7) << 3) | (iz & 7)));
         }
-        // newly occupied cells are staged in LDS and appended to occ_list in batches: C_OCC is one address for the whole
-        // chip (a same-address atomic retires every ~12 ns), so it gets one atomic per flush, not one per tile
-        if (first) s_occ[atomicAdd(&s_occ_n, 1u)] = slot;
-        __syncthreads();
-        if (s_occ_n > (unsigned)(kOccStage - 256)) flush_occ_stage(t, s_occ, s_occ_n, s_occ_base);  // block-uniform
+        // newly occupied cells are staged in LDS (per wave) and appended to occ_list in batches: C_OCC is one address for the
+        // whole chip (a same-address atomic retires every ~12 ns), so it gets one atomic per flush, not one per tile.  The
+        // count lives in a wave-uniform register, so no two waves ever have to agree on a flush (no barrier in the tile loop).
+        {
+            const unsigned long long fm = __ballot(first);
+            if (fm) {
+                if (occ_n + 64u > (uint32_t)kOccStage) {
+                    flush_occ_stage(t, s_occ, occ_n);
+                    occ_n = 0;
+                }
+                if (first) s_occ[occ_n + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = slot;
+                occ_n += (uint32_t)__popcll(fm);
+            }
+        }
 
         // buffer while the voxel has no normal (grid.hpp:210-211,230,239); the viewpoint latch (smallest frame
         // id that touched the cell, grid.hpp:229,238) is only ever read before the normal exists.
@@ -298,8 +312,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             wave_flush_members(t, q, member, d, sid);
         }
     }
-    __syncthreads();
-    if (s_occ_n) flush_occ_stage(t, s_occ, s_occ_n, s_occ_base);  // block-uniform
+    if (occ_n) flush_occ_stage(t, s_occ, occ_n);  // wave-uniform
     // block-level reduction of the diagnostics: one device atomic per counter per block
     uint32_t cv[6] = {c_present, c_z, c_in, c_buf, c_tested, c_member};
 #pragma unroll
@@ -789,7 +802,7 @@ __global__ __launch_bounds__(256) void k_dep_count(const Tables t, const uint64_
     }
     __shared__ BlockReserveScratch brs;
     const unsigned long long ti = block_reserve(&t.ctr[C_TOUCHED], fresh, brs);
-    if (fresh) t.touched_list[ti] = slot;  // capacity 2*max_reg >= n_reg + n_pre
+    if (fresh) t.touched_list[ti] = slot;  // capacity max_touched = max_reg >= distinct cells among n_reg + n_pre entries (host-checked: n_reg + n_pre <= max_reg)
 }
 
 __global__ __launch_bounds__(256) void k_dep_offsets(const Tables t, const uint64_t n_touched)

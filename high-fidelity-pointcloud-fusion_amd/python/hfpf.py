@@ -80,7 +80,7 @@ EXPORTS = [
     "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_write_pcd_xyzrgb", "hfpf_write_pcd_binary", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
     "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
     "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
-    "hfpf_dist_unique_id", "hfpf_dist_init", "hfpf_dist_disable", "hfpf_epoch_export", "hfpf_epoch_import", "hfpf_stats_export",
+    "hfpf_dist_unique_id", "hfpf_dist_init", "hfpf_dist_info", "hfpf_dist_disable", "hfpf_epoch_export", "hfpf_epoch_import", "hfpf_stats_export",
     "hfpf_extract_with_stats", "hfpf_device_download",
 ]
 
@@ -141,6 +141,7 @@ def lib():
     L.hfpf_dist_unique_id.argtypes = [vp]
     L.hfpf_dist_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.hfpf_dist_disable.argtypes = [vp]
+    L.hfpf_dist_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.hfpf_epoch_export.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.hfpf_epoch_import.argtypes = [vp, vp, u64]
     L.hfpf_stats_export.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
@@ -292,6 +293,12 @@ class OccupancyGrid:
         """unique_id: the 128 bytes rank 0 got from dist_unique_id(), broadcast by the launcher."""
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._chk(lib().hfpf_dist_init(self._h, rank, world, buf))
+
+    def dist_world(self):
+        """Rank count the engine's RCCL communicator reports (1 without a communicator)."""
+        r, w = C.c_int32(), C.c_int32()
+        self._chk(lib().hfpf_dist_info(self._h, C.byref(r), C.byref(w)))
+        return w.value
 
     def dist_disable(self):
         self._chk(lib().hfpf_dist_disable(self._h))

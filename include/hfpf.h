@@ -196,6 +196,8 @@ int hfpf_device_upload(hfpf_handle* h, void* dev_dst, const void* host_src, uint
  * torch.distributed/gloo, a C++ host would use MPI or a file), every rank calls hfpf_dist_init. */
 int hfpf_dist_unique_id(void* id128);
 int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128);
+/* Rank and rank count as the RCCL communicator reports them (ncclCommUserRank / ncclCommCount); 0 and 1 without one. */
+int hfpf_dist_info(hfpf_handle* h, int32_t* rank, int32_t* world);
 /* Drop the communicator again (e.g. when not every rank managed to create one); clean/extract become local calls. */
 int hfpf_dist_disable(hfpf_handle* h);
 /* Transport 2: bring your own.  The same exchange as explicit steps on device buffers (also how tests run several

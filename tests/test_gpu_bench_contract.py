@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "2",
-                          "--cpu-sample", "2", "--host-path-frames", "2"], capture_output=True, timeout=600, cwd=ROOT)
+                          "--frames-per-step", "4", "--repeats", "3", "--cpu-sample", "2", "--host-path-frames", "2"], capture_output=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly one line on stdout"
@@ -35,6 +35,12 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert d["cpu_baseline_all_cores"]["cores"] >= 1
     assert d["rows_extracted"] > 0
+    # 12 steps of 4 frames, clean every 3 steps: the steady state (dependant updates) is inside the timed region
+    assert d["config"]["points_per_step"] == 4 * 640 * 480 and d["config"]["frames"] == 48
+    assert d["repeats"] == 3 and len(d["pass_s"]) == 3 and d["value_min"] <= d["value"] <= d["value_max"]
+    assert d["clean_passes"] == 4 and d["counters"]["dep_pairs_tested"] > 0 and d["warnings"] == []
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["kernel_source_sha"] and r["traffic_source"]
 
 
 def test_bench_two_ranks_one_line_on_stdout():
@@ -43,13 +49,15 @@ def test_bench_two_ranks_one_line_on_stdout():
     fd 1; stdout must still carry exactly one JSON line, from rank 0."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2"],
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+                          "--frames-per-step", "4", "--repeats", "2"],
                          capture_output=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, "stdout must be exactly one line, got %d: %r" % (len(lines), lines[:3])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak"
-    assert d["config"]["points_per_step"] == 640 * 480
+    assert d["config"]["points_per_step"] == 4 * 640 * 480
+    assert "host-staged (gloo), 2 ranks" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
     assert d["value"] > 0 and d["rows_extracted"] > 0

@@ -109,3 +109,64 @@ def test_config5_grid_ten_cubic_metres(oracle_mod, hfpf_mod, synth_mod):
     og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=bbox)
     ref = scenes.run(og, sc, "capture")
     scenes.compare_rows(ref, rows)
+
+
+@pytest.mark.slow
+def test_config1_full_1000_frames(hfpf_mod, synth_mod):
+    """configs[1] at its full size: the 1000-frame 640x480 stream of bench.py (same seeds), clean every 150 frames + final
+    clean = 7 passes, dependant-table relocation at scale.  Too slow for the oracle, so: conservation checksums, sortedness,
+    and byte reproducibility between one integrate call per clean epoch (150 frames, bench.py's default) and 50 frames per call."""
+    sc = scenes.Scene(1000, 640, 480, 0.001, clean_every=150)
+    caps = dict(max_bricks=100000, max_log_points=96 << 20, max_normals=6 << 20, max_frames=2048, frame_width=640)
+    rows, ctr, dims = _stream(hfpf_mod, sc, 150, caps)
+    assert dims == (999, 999, 999)
+    assert ctr["points_presented"] == 1000 * 640 * 480 and ctr["frames_integrated"] == 1000 and ctr["clean_passes"] == 7
+    assert ctr["dep_pairs_tested"] > 5e8 and len(rows) > 1500000
+    _props(rows, ctr, dims)
+    rows2, ctr2, _ = _stream(hfpf_mod, sc, 50, caps)
+    assert rows.tobytes() == rows2.tobytes(), "1000-frame stream not byte-reproducible across frames_per_call 150 vs 50"
+    for k in ("points_zclip_pass", "points_in_bbox", "points_buffered", "dep_pairs_tested", "dep_pairs_member", "replay_members",
+              "voxels_occupied", "voxels_with_normal", "registrations"):
+        assert ctr[k] == ctr2[k], k
+
+
+def test_config4_shared_two_cubic_metre_grid_cameras_vs_oracle(oracle_mod, hfpf_mod, synth_mod):
+    """configs[3] shape: one camera per rank (distinct frame and pose seeds), shared 2 m^3 bbox @ 1 mm (1999x999x999 cells), merge
+    at every clean.  3 virtual ranks on one device against the oracle fed the union of the cameras' frames in canonical
+    (frame, camera) order; small frames so the oracle finishes in seconds."""
+    import hfpf_dist
+    bbox = (-1.0, 1.0, -0.5, 0.5, 0.0, 1.0)
+    world, n_frames, clean_every = 3, 4, 2
+    cams = [scenes.Scene(n_frames, 320, 240, 0.001, bbox=bbox, fx=615.0 / 2, seed=0xF051 + 7919 * r, pose_seed=0x5E3 + 104729 * r)
+            for r in range(world)]
+    caps = dict(max_bricks=100000, max_log_points=4 << 20, max_normals=1 << 20, max_frames=64)
+    og = oracle_mod.OracleGrid(resolution=0.001, bbox=bbox)
+    grids = [hfpf_mod.OccupancyGrid(resolution=0.001, bbox=bbox, **caps) for _ in range(world)]
+    vr = hfpf_dist.LocalVirtualRanks(grids)
+    fb = 320 * 240 * 16
+    devs = [g.device_alloc(fb) for g in grids]
+    try:
+        assert grids[0].dims[0] == (1999, 999, 999)
+        for f in range(n_frames):
+            for r in range(world):
+                buf = cams[r].frame(f)
+                og.capture(buf, cams[r].poses[f])
+                grids[r].device_upload(devs[r], buf)
+                grids[r].integrate_device(devs[r], 1, fb, 320 * 240, cams[r].poses[f][None], frame_ids=np.array([f * world + r], np.uint32))
+                grids[r].sync()
+            if (f + 1) % clean_every == 0 and f + 1 < n_frames:
+                vr.clean_all()
+                og.clean()
+        vr.clean_all()
+        og.clean()
+        ref = og.extract()
+        for on in range(world):  # every rank extracts the same merged cloud
+            rows = vr.extract(on=on)
+            scenes.compare_rows(ref, rows)
+        assert len(ref) > 20000
+        occ = grids[0].occupied()
+        assert np.array_equal(og.occupied(), occ)
+    finally:
+        for g, d in zip(grids, devs):
+            g.device_free(d)
+            g.close()

@@ -49,6 +49,17 @@ def test_node_state_machine_and_outputs(tmp_path, oracle_mod, hfpf_mod, synth_mo
         # ~process does NOT clean first in the reference (node.cpp:377-398): frame 4 only updates dependants
         rc, ok, msg = node.process()
         assert rc == 0 and ok and "test_cloud.pcd" in msg
+        # the files of THIS process call against the oracle driven through the same events
+        ref = og.extract()
+        hdr, data = pcd_io.read_pcd_ascii(str(tmp_path / "test_cloud.pcd"))
+        header, meta = pcd_io.read_meta_csv(str(tmp_path / "meta.csv"))
+        assert len(ref) > 0 and int(hdr["POINTS"]) == len(ref) == data.shape[0] == meta.shape[0]
+        assert "saved %d points" % len(ref) in msg
+        for j, f in enumerate(("x", "y", "z")):
+            assert np.abs(data[:, j] - ref[f]).max() <= 1e-5
+        for j, f in zip((4, 5, 6), ("nx", "ny", "nz")):
+            assert np.allclose(data[:, j], ref[f], rtol=1e-7, atol=0)  # bit-identical normals, printed with 8 digits
+        assert np.array_equal(meta[:, 6], ref["count"])
         st = node.stats()
         assert (st["received"], st["integrated"], st["dropped_not_started"], st["dropped_tf"]) == (8, 5, 2, 1)
         # the grid was cleared (clearVoxels, node.cpp:438): a second process emits nothing
@@ -57,7 +68,6 @@ def test_node_state_machine_and_outputs(tmp_path, oracle_mod, hfpf_mod, synth_mo
         # ~reset stops capture but leaves the grid alone (node.cpp:351-359)
         rc, ok, _ = node.reset()
         assert ok and node.stats()["started"] == 0 and node.stats()["cloud_subscription_started"] == 0
-    ref = og.extract()
     hdr, data = pcd_io.read_pcd_ascii(str(tmp_path / "test_cloud.pcd"))
     header, meta = pcd_io.read_meta_csv(str(tmp_path / "meta.csv"))
     # the second (empty) process overwrote the files, as the reference would
