@@ -35,7 +35,7 @@ struct GridParams {
     int32_t gate;                 // grid.hpp:352
     int32_t cov_shifted;          // 0: PCL <= 1.10 single-pass moments; 1: PCL >= 1.11 moments of (p - first point)
     // fixed-point scales (powers of two) of the order-free statistic sums, see stats.hpp
-    double s1_scale, s2_scale, sd_scale, sdd_scale;
+    float fs_scale, fss_scale, fd_scale, fdd_scale;
 };
 
 HFPF_HD float sum3(float a, float b, float c) { return a + (b + c); }  // Eigen fixed-size-3 redux: c0 + (c1 + c2)
@@ -110,20 +110,39 @@ HFPF_HD F3 voxel_center(const GridParams& g, int32_t x, int32_t y, int32_t z)
     return c;
 }
 
-// grid.hpp:40-49 projectPointToVector + grid.hpp:261-262 (norm widened to double, compared with
-// kCylinderRadius).  Returns membership; proj and dist are outputs.
-HFPF_HD bool cylinder_member(const GridParams& g, F3 pt, F3 centre, F3 n, F3& proj, double& dist)
+// grid.hpp:40-49 projectPointToVector + grid.hpp:261-262 (norm widened to double, compared with kCylinderRadius), split in
+// two: what depends only on the voxel whose line it is (segment end a = centre - r*n, ab = a - b, |ab|^2: computed once per
+// normal record and kept in its dependant entries) and what depends on the point.  The f32 operations and their order are the
+// reference's; only the place where the per-voxel half is evaluated differs.
+HFPF_HD void line_of(const GridParams& g, F3 centre, F3 n, F3& a, F3& ab, float& dd)
 {
     const F3 d_xyz = mul3(g.ball_r, n);
-    const F3 a = sub3(centre, d_xyz);
+    a = sub3(centre, d_xyz);
     const F3 b = add3(centre, d_xyz);
+    ab = sub3(a, b);
+    dd = dot3(ab, ab);
+}
+
+// s = the projection parameter (proj = a - s*ab, so s = 0.5 at the cell centre); distf = ||pt - proj|| in f32.
+HFPF_HD bool line_member(const GridParams& g, F3 pt, F3 a, F3 ab, float dd, float& s, F3& proj, float& distf)
+{
     const F3 ap = sub3(a, pt);
-    const F3 ab = sub3(a, b);
-    const float s = dot3(ap, ab) / dot3(ab, ab);
+    s = dot3(ap, ab) / dd;
     proj = sub3(a, mul3(s, ab));
     const F3 df = sub3(pt, proj);
-    dist = (double)sqrtf(dot3(df, df));
-    return dist < g.cyl_r;
+    distf = sqrtf(dot3(df, df));
+    return (double)distf < g.cyl_r;
+}
+
+// The reference's form (used by the leaf probes): returns membership; proj and dist are outputs.
+HFPF_HD bool cylinder_member(const GridParams& g, F3 pt, F3 centre, F3 n, F3& proj, double& dist)
+{
+    F3 a, ab;
+    float dd, s, distf;
+    line_of(g, centre, n, a, ab, dd);
+    const bool m = line_member(g, pt, a, ab, dd, s, proj, distf);
+    dist = (double)distf;
+    return m;
 }
 
 // ---- plane fit: pcl::computeMeanAndCovarianceMatrix + pcl::eigen33 (call sites grid.hpp:302,289) ----

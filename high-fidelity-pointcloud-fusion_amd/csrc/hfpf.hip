@@ -112,7 +112,7 @@ struct hfpf_handle {
     void* rccl_lib = nullptr;
     void* comm = nullptr;  // ncclComm_t
     uint64_t occ_exported = 0;  // occ_list entries already exchanged
-    DevBuf ex_send, ex_recv, ex_counts, stats_total, cstats_total;
+    DevBuf ex_send, ex_recv, ex_counts, stats_total;
     unsigned long long* h_counts = nullptr;  // pinned, world entries
 
     // kernel timing
@@ -203,6 +203,13 @@ int read_counters(hfpf_handle* h)
         upd_tested += h->h_log_ctr[r * 16 + 2];
         upd_member += h->h_log_ctr[r * 16 + 3];
     }
+#ifdef HFPF_ABL
+    {
+        unsigned long long it = 0;
+        for (int r = 0; r < kLogRegions; r++) it += h->h_log_ctr[r * 16 + 4];
+        if (getenv("HFPF_ABL_PRINT")) fprintf(stderr, "[abl] k_update wave-iterations %llu, pairs tested %llu, lane utilisation %.3f\n", it, upd_tested, it ? (double)upd_tested / (64.0 * (double)it) : 0.0);
+    }
+#endif
     h->h_ctr[C_DEP_TESTED] += upd_tested;
     h->h_ctr[C_DEP_MEMBER] += upd_member;
     h->n_bricks_known = std::min<uint64_t>(h->h_ctr[C_BRICKS], h->t.max_bricks);
@@ -226,7 +233,8 @@ int check_device_errors(hfpf_handle* h)
     return fail(h, HFPF_ERR_CAPACITY, "device pool overflow:%s", what.c_str());
 }
 
-int pow2_exponent_for(double bound) { return 38 - (int)std::ceil(std::log2(bound)); }
+// Power-of-two scale that keeps one contribution of magnitude < bound below 2^27 (stats.hpp).
+float stat_scale_for(double bound) { return (float)std::ldexp(1.0, 26 - (int)std::floor(std::log2(bound))); }
 
 int setup_params(hfpf_handle* h)
 {
@@ -255,11 +263,14 @@ int setup_params(hfpf_handle* h)
     g.K = c.K;
     g.gate = c.gate;
     g.cov_shifted = (c.flags & HFPF_FLAG_PCL_SHIFTED_COV) ? 1 : 0;
-    const double B = ((double)c.K + 2.0) * g.res;  // |proj - c| <= |p - c| <= K*res + sqrt(3)*res
-    g.s1_scale = std::ldexp(1.0, pow2_exponent_for(B));
-    g.s2_scale = std::ldexp(1.0, pow2_exponent_for(B * B));
-    g.sd_scale = std::ldexp(1.0, pow2_exponent_for(g.cyl_r));
-    g.sdd_scale = std::ldexp(1.0, pow2_exponent_for(g.cyl_r * g.cyl_r));
+    // s = 0.5 + t / (2 r) with t the point's offset along the normal from the cell centre: a point updates a voxel only from
+    // a cell on that voxel's line, so |t| <= K*res + sqrt(3)*res
+    const double Bs = 0.5 + ((double)c.K + 2.0) * g.res / (2.0 * c.ball_radius);
+    if (!(Bs < 1.0e6)) return fail(h, HFPF_ERR_BAD_CONFIG, "ball_radius too small for this resolution and K");
+    g.fs_scale = stat_scale_for(Bs);
+    g.fss_scale = stat_scale_for(Bs * Bs);
+    g.fd_scale = stat_scale_for(g.cyl_r);
+    g.fdd_scale = stat_scale_for(g.cyl_r * g.cyl_r);
     const double dir_entries = (double)g.bdim[0] * (double)g.bdim[1] * (double)g.bdim[2];
     if (dir_entries > 4.0e9) return fail(h, HFPF_ERR_BAD_CONFIG, "brick directory too large (%.3g entries)", dir_entries);
     h->dir_entries = (size_t)dir_entries;
@@ -279,7 +290,7 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.dep_tmp, 0, h->n_slots * 4, s));
     HIPCHK(h, hipMemsetAsync(t.occ_mask, 0, (t.max_bricks + 1) * 8 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.stats, 0, (t.max_normals + 1) * kStatWords * 8, s));
-    if (t.cstats) HIPCHK(h, hipMemsetAsync(t.cstats, 0, (t.max_normals + 1) * 4 * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.nd_mask, 0, (t.max_bricks + 1) * 8 * 2 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.ctr, 0, C_COUNT * 8, s));
     HIPCHK(h, hipMemsetAsync(t.log_ctr, 0, kLogRegions * 16 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.bin_fill, 0, (t.max_bricks + 2) * 4, s));
@@ -341,7 +352,9 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(nv_c, 3 * (t.max_normals + 1), 0, false);
     ALLOC(nv_n, 3 * (t.max_normals + 1), 0, false);
     ALLOC(stats, (t.max_normals + 1) * kStatWords, 0, false);
-    if (c.flags & HFPF_FLAG_FUSE_COLOR) { ALLOC(cstats, (t.max_normals + 1) * 4, 0, false); }
+    t.color = (c.flags & HFPF_FLAG_FUSE_COLOR) ? 1u : 0u;
+    ALLOC(nv_line, 2 * (t.max_normals + 1), 0, false);
+    ALLOC(nd_mask, (t.max_bricks + 1) * 8 * 2, 0, false);
     ALLOC(reg_occ, t.max_reg, 0, false);
     ALLOC(dep, t.max_dep, 0, false);
     ALLOC(prereg_list, t.max_reg, 0, false);
@@ -467,7 +480,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         HIPCHK(h, get(e1));
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
-    const bool color = h->t.cstats != nullptr;
+    const bool color = h->t.color != 0;
     const bool bin = h->binned;
     const uint32_t nb = (uint32_t)h->n_bricks_known;
     const bool demand_only = h->h_ctr[C_NORMALS] == 0;  // as of the last clean: nothing can have dependants yet
@@ -804,7 +817,7 @@ int clean_locked(hfpf_handle* h)
         // (brick-major) order lets adjacent lanes share cache lines of the log
         if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
         if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched))) return rc;
-        if (t.cstats)
+        if (t.color)
             hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
         else
             hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
@@ -890,7 +903,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
             const uint64_t pts = h->cfg.max_call_points;
             const uint64_t pool = std::min<uint64_t>(pts + pts / 3 + 64ull * (h->cfg.max_bricks + 1), 0xFFFFFFFFull);
             if ((rc = scratch(h, h->bin_pt_buf, pool * sizeof(float4)))) return bail(rc);
-            if (h->t.cstats && (rc = scratch(h, h->bin_rgb_buf, pool * 4))) return bail(rc);
+            if (h->t.color && (rc = scratch(h, h->bin_rgb_buf, pool * 4))) return bail(rc);
             h->bin_pool = pool;
         }
     }
@@ -908,7 +921,7 @@ int hfpf_destroy(hfpf_handle* h)
     for (DevBuf* b : {&h->sort_tmp, &h->keys_a, &h->keys_b, &h->vals_a, &h->vals_b, &h->rows_dev, &h->probe_a, &h->probe_b, &h->probe_c, &h->probe_d,
                       &h->probe_e, &h->probe_f})
         if (b->p) (void)hipFree(b->p);
-    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->cstats_total, &h->bin_pt_buf, &h->bin_rgb_buf, &h->pend_a, &h->pend_b})
+    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->bin_pt_buf, &h->bin_rgb_buf, &h->pend_a, &h->pend_b})
         if (b->p) (void)hipFree(b->p);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t_)h->comm);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
@@ -1029,8 +1042,8 @@ int hfpf_clean(hfpf_handle* h)
     return rc;
 }
 
-// Shared tail of extract: `stats` / `cstats` are the (possibly merged) sums to finalise.
-static int extract_locked(hfpf_handle* h, const unsigned long long* stats, const unsigned long long* cstats, hfpf_row** rows, uint64_t* n_rows)
+// Shared tail of extract: `stats` are the (possibly merged) sums to finalise.
+static int extract_locked(hfpf_handle* h, const unsigned long long* stats, hfpf_row** rows, uint64_t* n_rows)
 {
     Tables& t = h->t;
     int rc;
@@ -1048,7 +1061,7 @@ static int extract_locked(hfpf_handle* h, const unsigned long long* stats, const
     const uint64_t nr = h->h_ctr[C_ROWS];
     if (nr == 0) return HFPF_OK;
     if ((rc = scratch(h, h->rows_dev, nr * sizeof(Row)))) return rc;
-    hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, stats, cstats, nr, (const uint64_t*)h->keys_b.p,
+    hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, stats, nr, (const uint64_t*)h->keys_b.p,
                        (const uint32_t*)h->vals_b.p, (Row*)h->rows_dev.p);
     HIPCHK(h, hipGetLastError());
     hfpf_row* host = (hfpf_row*)malloc(nr * sizeof(hfpf_row));
@@ -1076,7 +1089,6 @@ int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
     if (rc) return rc;
     if ((rc = check_device_errors(h))) return rc;
     const unsigned long long* stats = t.stats;
-    const unsigned long long* cstats = t.cstats;
     if (h->dist_on) {
         // Sum the ranks' private partial records (exact integer adds) into scratch; the partials stay intact.
         // Normal records are replicated, so every rank holds the same n and the same record ids.
@@ -1084,14 +1096,8 @@ int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
         if ((rc = scratch(h, h->stats_total, words * 8))) return rc;
         NCCLCHK(h, g_rccl.AllReduce(t.stats, h->stats_total.p, words, ncclUint64_, ncclSum_, (ncclComm_t_)h->comm, h->stream));
         stats = (const unsigned long long*)h->stats_total.p;
-        if (t.cstats) {
-            const uint64_t cwords = (h->h_ctr[C_NORMALS] + 1) * 4;
-            if ((rc = scratch(h, h->cstats_total, cwords * 8))) return rc;
-            NCCLCHK(h, g_rccl.AllReduce(t.cstats, h->cstats_total.p, cwords, ncclUint64_, ncclSum_, (ncclComm_t_)h->comm, h->stream));
-            cstats = (const unsigned long long*)h->cstats_total.p;
-        }
     }
-    return extract_locked(h, stats, cstats, rows, n_rows);
+    return extract_locked(h, stats, rows, n_rows);
 }
 
 int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* dev_cwords, hfpf_row** rows, uint64_t* n_rows)
@@ -1104,7 +1110,8 @@ int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* d
     int rc = read_counters(h);
     if (rc) return rc;
     if ((rc = check_device_errors(h))) return rc;
-    return extract_locked(h, (const unsigned long long*)dev_words, h->t.cstats ? (const unsigned long long*)dev_cwords : nullptr, rows, n_rows);
+    (void)dev_cwords;  // colour sums travel in words 5-7 of the statistics records since ABI 3
+    return extract_locked(h, (const unsigned long long*)dev_words, rows, n_rows);
 }
 
 int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words, const void** dev_cwords, uint64_t* n_cwords)
@@ -1116,8 +1123,8 @@ int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words,
     if (rc) return rc;
     *dev_words = h->t.stats;
     *n_words = (h->h_ctr[C_NORMALS] + 1) * kStatWords;
-    if (dev_cwords) *dev_cwords = h->t.cstats;
-    if (n_cwords) *n_cwords = h->t.cstats ? (h->h_ctr[C_NORMALS] + 1) * 4 : 0;
+    if (dev_cwords) *dev_cwords = nullptr;  // colour sums are words 5-7 of the same records
+    if (n_cwords) *n_cwords = 0;
     return HFPF_OK;
 }
 

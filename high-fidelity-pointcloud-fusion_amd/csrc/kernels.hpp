@@ -51,13 +51,14 @@ constexpr uint64_t kCountOnDevice = ~0ull;
 constexpr int kListTiles = 4;  // same idea for the k_depinc_* list builders (not k_gate: it is latency-heavy per cell and needs every workgroup it can get)
 typedef float vf4 __attribute__((ext_vector_type(4)));  // native vector type (the nontemporal builtins do not take HIP's float4)
 
-// Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (7 words + record id + rgb sums)
+// Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (5 words, + 3 colour sums, + record id)
 // in the wave's LDS queue, then the wave replays the queue with 8 lanes per record, so one wave-instruction
 // carries 8 whole 64-byte records (one memory-side atomic segment each).  Convergent (all 64 lanes must call).
 constexpr int kQueueStride = 11;  // u64 words per queued delta; odd stride spreads LDS banks
 template <bool COLOR>
 __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned long long* q, bool member, const StatDeltaT<COLOR>& d, uint32_t sid)
 {
+    constexpr int W = COLOR ? 8 : kStatUsed;
     const unsigned long long mm = __ballot(member);
     if (mm == 0) return;
     const uint32_t lane = lane_id();
@@ -66,13 +67,13 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
         const uint32_t row = (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
         unsigned long long* r = q + row * kQueueStride;
 #pragma unroll
-        for (int w = 0; w < SW_USED; w++) r[w] = (unsigned long long)d.v[w];
-        r[7] = sid;
+        for (int w = 0; w < kStatUsed; w++) r[w] = (unsigned long long)d.v[w];
         if constexpr (COLOR) {
-            r[8] = (unsigned long long)d.rgb[0];
-            r[9] = (unsigned long long)d.rgb[1];
-            r[10] = (unsigned long long)d.rgb[2];
+            r[SW_R] = (unsigned long long)d.rgb[0];
+            r[SW_G] = (unsigned long long)d.rgb[1];
+            r[SW_B] = (unsigned long long)d.rgb[2];
         }
+        r[8] = sid;
     }
     // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -81,19 +82,9 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
         const uint32_t w = lane & 7u;
         for (uint32_t r0 = 0; r0 < n_mem; r0 += 8) {
             const uint32_t row = r0 + (lane >> 3);
-            if (row < n_mem && w < SW_USED) {
+            if (row < n_mem && w < (uint32_t)W) {
                 const unsigned long long* r = q + row * kQueueStride;
-                atomicAdd(&t.stats[(uint64_t)r[7] * kStatWords + w], r[w]);
-            }
-        }
-    }
-    if (COLOR) {  // optional colour fusion: 4 lanes per record, 16 records per wave-instruction
-        const uint32_t w = lane & 3u;
-        for (uint32_t r0 = 0; r0 < n_mem; r0 += 16) {
-            const uint32_t row = r0 + (lane >> 2);
-            if (row < n_mem && w < 3) {
-                const unsigned long long* r = q + row * kQueueStride;
-                atomicAdd(&t.cstats[(uint64_t)r[7] * 4 + w], r[8 + w]);
+                atomicAdd(&t.stats[(uint64_t)r[8] * kStatWords + w], r[w]);
             }
         }
     }
@@ -203,16 +194,28 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         const uint32_t bidx = act ? brick_index(g, ix, iy, iz) : 0u;
         const uint32_t b = brick_acquire_wave(t, bidx, act);
         act = act && b != 0;
-        const uint32_t slot = b * kBrickCells + local_index(ix, iy, iz);
-        const uint64_t info = act ? t.info[slot] : 0ull;
+        const uint32_t lcell = local_index(ix, iy, iz);
+        const uint32_t slot = b * kBrickCells + lcell;
+        // What to do with the point is two bits of its cell: normal_found (stop buffering, grid.hpp:210) and has-dependants.
+        // Both come from the brick's 128-byte flag line (L2-resident) instead of the cell's 8-byte info word.
+        const uint64_t plane = (uint64_t)b * 8u + ((uint32_t)ix & 7u);
+        const uint64_t bit = 1ull << ((((uint32_t)iy & 7u) << 3) | ((uint32_t)iz & 7u));
+        bool has_n = false, has_d = false;
+        if (act) {
+            const ulonglong2 nd = *reinterpret_cast<const ulonglong2*>(&t.nd_mask[plane * 2]);
+            has_n = (nd.x & bit) != 0;
+            has_d = (nd.y & bit) != 0;
+        }
 
-        // first occupancy (grid.hpp:219-243)
+        // first occupancy (grid.hpp:219-243): the returning atomic on the brick's occupancy word decides who is first
         bool first = false;
-        if (act && !(info & kOcc)) {
-            const unsigned int old = atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
-            first = !(old & 1u);
-            if (first) atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (ix & 7)]),
-                                1ull << (((iy & 7) << 3) | (iz & 7)));
+        if (act && !has_n) {
+            unsigned long long* om = reinterpret_cast<unsigned long long*>(&t.occ_mask[plane]);
+            if (!(*om & bit)) {  // a stale (cached) word only sends the lane through the atomic
+                const unsigned long long old = atomicOr(om, (unsigned long long)bit);
+                first = !(old & bit);
+                if (first) atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
+            }
         }
         // newly occupied cells are staged in LDS (per wave) and appended to occ_list in batches: C_OCC is one address for the
         // whole chip (a same-address atomic retires every ~12 ns), so it gets one atomic per flush, not one per tile.  The
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 
         // buffer while the voxel has no normal (grid.hpp:210-211,230,239); the viewpoint latch (smallest frame
         // id that touched the cell, grid.hpp:229,238) is only ever read before the normal exists.
-        const bool buf = act && !(info & kNormal);
+        const bool buf = act && !has_n;
         if (buf && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
         const unsigned long long li = wave_reserve(log_ctr, buf);
         if (buf) {
@@ -246,14 +249,13 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         c_buf += buf;
 
         // dependant updates (grid.hpp:244-277)
-        uint32_t cnt = act ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u;
-        const uint64_t off = info >> kDepOffShift;
+        bool direct = act && has_d;  // still to be handled by this kernel
         if (BIN) {
             // Two-pass form: park the point in its brick's bin; k_update accumulates every brick's records in LDS and
             // flushes each record once per launch instead of once per (point, dependant) pair.  One reservation per
-            // distinct brick per wave (ballot grouping); a lane whose brick region is full (or unplanned) keeps cnt and
-            // takes the direct path below, so correctness never depends on the plan.
-            const bool want_bin = cnt > 0 || (act && t.bin_demand_only);
+            // distinct brick per wave (ballot grouping); a lane whose brick region is full (or unplanned) stays `direct`
+            // and takes the loop below, so correctness never depends on the plan.
+            const bool want_bin = direct || (act && t.bin_demand_only);
             // phase 1 (registers only): group the lanes by brick -> leader lane, rank in group, group size
             uint32_t grp_leader = lane, grp_rank = 0, grp_size = 0;
             unsigned long long m = __ballot(want_bin);
@@ -279,15 +281,22 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             base = __shfl(base, (int)grp_leader);
             cap = __shfl(cap, (int)grp_leader);
             roff = __shfl(roff, (int)grp_leader);
-            if (want_bin && cnt > 0) {
+            if (direct) {
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
                     const uint64_t e = (uint64_t)roff + pos;
-                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t)off));  // the point + where its dependant list starts; read back once by k_update
+                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(lcell));  // the point + its cell inside the brick; read back once by k_update
                     if (COLOR) t.bin_rgb[e] = rgb;
-                    cnt = 0;  // handled by k_update
+                    direct = false;  // handled by k_update
                 }
             }
+        }
+        uint32_t cnt = 0;
+        uint64_t off = 0;
+        if (direct) {
+            const uint64_t info = t.info[slot];
+            cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+            off = info >> kDepOffShift;
         }
         uint32_t max_cnt = cnt;
 #pragma unroll
@@ -295,18 +304,18 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         for (uint32_t j = 0; j < max_cnt; j++) {
             bool member = false;
             StatDeltaT<COLOR> d;
+            stat_delta_zero(d);
             uint32_t sid = 0;
             if (j < cnt) {
                 const DepEntry e = t.dep[off + j];
                 F3 proj;
-                double dist;
+                float sp, distf;
                 c_tested++;
-                if (cylinder_member(g, p, F3{e.cx, e.cy, e.cz}, F3{e.nx, e.ny, e.nz}, proj, dist)) {
+                if (line_member(g, p, F3{e.ax, e.ay, e.az}, F3{e.abx, e.aby, e.abz}, e.dd, sp, proj, distf)) {
                     member = true;
                     c_member++;
                     sid = e.sid;
-                    stat_delta_zero(d);
-                    stat_delta_add(d, g, proj, F3{e.cx, e.cy, e.cz}, dist, rgb);
+                    stat_delta_add(d, pair_delta(g, sp, distf), rgb);
                 }
             }
             wave_flush_members(t, q, member, d, sid);
@@ -334,88 +343,244 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 
 
 // ------------------------------------------------------------------------------------------------
-// K2 (binned form): one workgroup per brick.  The brick's parked points are read back coalesced; every
-// (point, dependant) member pair adds its 7-word delta to an LDS table keyed by record id (open addressing,
-// LDS atomics), and the table is flushed with the same 8-lanes-per-record cooperative atomics, so a record costs
-// one memory-side request per brick per launch.  A full table falls back to direct device atomics.
+// K2 (binned form): one workgroup per brick.
+//
+//   1. The brick's parked points are read back coalesced and counting-sorted by cell in LDS (one returning LDS atomic per
+//      point gives its rank inside the cell; a 512-entry scan gives the cells' runs), kUpdCap points per round.
+//   2. A "row" of kUpdRow lanes takes up to kUpdRow points of ONE cell.  Every lane of a row walks the same dependant list,
+//      so a dependant entry is one broadcast 32-byte read per row instead of one scattered read per lane (the per-lane
+//      form was bound by the vector L1's access rate: 4.4e8 accesses per launch), and the loop count is the same for
+//      the whole row.
+//   3. The members' contributions (four integers < 2^27, stats.hpp) are summed across the row with DPP adds in 32 bits;
+//      the row's first lane adds the row sum to an LDS table keyed by record id -- kUpdRow times fewer LDS atomics, none
+//      of them on the same address from one wave-instruction.
+//   4. The table is flushed with 8 lanes per record: one 64-byte memory-side request per record per brick per launch.
+//      A full table falls back to direct device atomics.
 #ifndef HFPF_UPD_BITS
 #define HFPF_UPD_BITS 9  // log2 of the LDS table size of k_update
 #endif
+#ifndef HFPF_UPD_ROW
+#define HFPF_UPD_ROW 16  // lanes per row (8 or 16)
+#endif
+#ifndef HFPF_UPD_PER
+#define HFPF_UPD_PER 7   // points a thread holds in registers while a round is sorted
+#endif
 constexpr int kUpdSlots = 1 << HFPF_UPD_BITS;
+constexpr int kUpdRow = HFPF_UPD_ROW;
+constexpr int kUpdPer = HFPF_UPD_PER;
+constexpr int kUpdCap = 256 * kUpdPer;                  // points sorted per round
+constexpr int kUpdRows = 256 / kUpdRow;                 // rows per workgroup
+constexpr int kUpdItems = kUpdCap / kUpdRow + kBrickCells;  // (cell, up-to-kUpdRow points) work items per round, worst case
+static_assert(kUpdRow == 8 || kUpdRow == 16, "row width");
+static_assert(kUpdCap <= 4096, "item encoding holds 12 bits of start");
 __device__ __forceinline__ uint32_t upd_hash(uint32_t sid) { return (sid * 2654435761u) >> (32 - HFPF_UPD_BITS); }
+
+// Sum over the lanes of a row (every lane receives the sum).  DPP: quad_perm xor 1, xor 2, then rotate across the quads.
+template <int CTRL>
+__device__ __forceinline__ int dpp_get(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int row_sum(int v)
+{
+    v += dpp_get<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (kUpdRow == 16) {
+        v += dpp_get<0x124>(v);  // row_ror:4
+        v += dpp_get<0x128>(v);  // row_ror:8
+    } else {
+        v += dpp_get<0x141>(v);  // row_half_mirror: lane i <-> 7-i of each 8-lane half
+    }
+    return v;
+}
 
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables t, const uint32_t n_bricks)
 {
+    constexpr int W = COLOR ? 8 : kStatUsed;
+    __shared__ uint32_t s_hist[kBrickCells];  // points per cell, then first sorted position of the cell's run
+    __shared__ uint16_t s_cnt[kBrickCells];   // dependants per cell
+    __shared__ uint32_t s_off[kBrickCells];   // start of the cell's dependant list in dep[]
+    __shared__ float s_px[kUpdCap], s_py[kUpdCap], s_pz[kUpdCap];
+    __shared__ uint32_t s_rgb[COLOR ? kUpdCap : 1];
+    __shared__ uint32_t s_item[kUpdItems];    // start | (points - 1) << 12 | cell << 16
+    __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t keys[kUpdSlots];
-    __shared__ unsigned long long vals[kUpdSlots * SW_USED];
-    __shared__ unsigned long long cvals[COLOR ? kUpdSlots * 3 : 1];
+    __shared__ unsigned long long vals[kUpdSlots * W];
     __shared__ unsigned int blk_ctr[2];
     const uint32_t b = blockIdx.x + 1;
     if (b > n_bricks) return;
     const uint32_t fill = min(t.bin_fill[b], t.bin_capb[b]);
     if (fill == 0) return;  // block-uniform
-    for (uint32_t i = threadIdx.x; i < kUpdSlots; i += 256) keys[i] = 0;
-    for (uint32_t i = threadIdx.x; i < kUpdSlots * SW_USED; i += 256) vals[i] = 0;
-    if (COLOR)
-        for (uint32_t i = threadIdx.x; i < kUpdSlots * 3; i += 256) cvals[i] = 0;
-    if (threadIdx.x < 2) blk_ctr[threadIdx.x] = 0;
-    __syncthreads();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += 256) {
+        const uint64_t info = t.info[(uint64_t)b * kBrickCells + i];
+        s_cnt[i] = (uint16_t)((info >> kDepCntShift) & kDepCntMask);
+        s_off[i] = (uint32_t)(info >> kDepOffShift);  // < 2^32, checked at create
+    }
+    for (uint32_t i = tid; i < (uint32_t)kUpdSlots; i += 256) keys[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t)(kUpdSlots * W); i += 256) vals[i] = 0;
+    if (tid < 2) blk_ctr[tid] = 0;
     const uint64_t first = t.bin_off[b];
     uint32_t c_tested = 0, c_member = 0;
-    for (uint32_t i = threadIdx.x; i < fill; i += 256) {
-        const float4 pe = t.bin_pt[first + i];
-        const uint32_t rgb = COLOR ? t.bin_rgb[first + i] : 0u;
-        const F3 p = F3{pe.x, pe.y, pe.z};
-        const uint64_t off = __float_as_uint(pe.w);  // start of the point's dependant list (< 2^32, checked at create)
-        uint32_t cnt = 1;
-        for (uint32_t j = 0; j < cnt; j++) {
-            const DepEntry e = t.dep[off + j];
-            if (j == 0) cnt = e.pad;  // the first entry of a list carries its length
-            F3 proj;
-            double dist;
-            c_tested++;
-            if (!cylinder_member(g, p, F3{e.cx, e.cy, e.cz}, F3{e.nx, e.ny, e.nz}, proj, dist)) continue;
-            c_member++;
-            StatDeltaT<COLOR> d;
-            stat_delta_zero(d);
-            stat_delta_add(d, g, proj, F3{e.cx, e.cy, e.cz}, dist, rgb);
-            uint32_t h = upd_hash(e.sid);
-            bool placed = false;
-            for (int probe = 0; probe < 16; probe++) {
-                const uint32_t old = atomicCAS(&keys[h], 0u, e.sid);
-                if (old == 0u || old == e.sid) {
-                    placed = true;
-                    break;
-                }
-                h = (h + 1) & (kUpdSlots - 1);
+#ifdef HFPF_ABL
+    uint32_t c_iter = 0;
+#endif
+    const uint32_t row = tid / kUpdRow, rl = tid % kUpdRow;
+
+    for (uint32_t chunk = 0; chunk < fill; chunk += (uint32_t)kUpdCap) {  // block-uniform trip count
+        const uint32_t n = min((uint32_t)kUpdCap, fill - chunk);
+        for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += 256) s_hist[i] = 0;
+        __syncthreads();
+        // 1. read the round's points, rank each inside its cell
+        float4 e[kUpdPer];
+        uint32_t rk[kUpdPer], crgb[COLOR ? kUpdPer : 1];
+#pragma unroll
+        for (int k = 0; k < kUpdPer; k++) {
+            const uint32_t i = tid + 256u * (uint32_t)k;
+            e[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rk[k] = 0;
+            if (i < n) {
+                e[k] = t.bin_pt[first + chunk + i];
+                if (COLOR) crgb[k] = t.bin_rgb[first + chunk + i];
             }
-            if (placed) {
+        }
 #pragma unroll
-                for (int w = 0; w < SW_USED; w++) atomicAdd(&vals[h * SW_USED + w], (unsigned long long)d.v[w]);
-                if constexpr (COLOR) {
-                    atomicAdd(&cvals[h * 3 + 0], (unsigned long long)d.rgb[0]);
-                    atomicAdd(&cvals[h * 3 + 1], (unsigned long long)d.rgb[1]);
-                    atomicAdd(&cvals[h * 3 + 2], (unsigned long long)d.rgb[2]);
+        for (int k = 0; k < kUpdPer; k++) {
+            const uint32_t i = tid + 256u * (uint32_t)k;
+            if (i < n) rk[k] = atomicAdd(&s_hist[__float_as_uint(e[k].w) & (kBrickCells - 1)], 1u);
+        }
+        __syncthreads();
+        // 2. runs and work items: thread t owns cells 2t and 2t+1; points and items share one packed scan
+        {
+            const uint32_t c0 = 2u * tid, c1 = c0 + 1u;
+            const uint32_t h0 = s_hist[c0], h1 = s_hist[c1];
+            const uint32_t it0 = s_cnt[c0] ? (h0 + kUpdRow - 1) / kUpdRow : 0u;  // cells without dependants need no work
+            const uint32_t it1 = s_cnt[c1] ? (h1 + kUpdRow - 1) / kUpdRow : 0u;
+            const uint32_t packed = (h0 + h1) | ((it0 + it1) << 16);
+            uint32_t incl = packed;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if (lane >= (uint32_t)o) incl += v;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; w++) before += s_wsum[w];
+            const uint32_t excl = before + incl - packed;
+            const uint32_t p0 = excl & 0xFFFFu, i0 = excl >> 16;
+            s_hist[c0] = p0;
+            s_hist[c1] = p0 + h0;
+            for (uint32_t k = 0; k < it0; k++) s_item[i0 + k] = (p0 + k * kUpdRow) | ((min((uint32_t)kUpdRow, h0 - k * kUpdRow) - 1u) << 12) | (c0 << 16);
+            for (uint32_t k = 0; k < it1; k++)
+                s_item[i0 + it0 + k] = (p0 + h0 + k * kUpdRow) | ((min((uint32_t)kUpdRow, h1 - k * kUpdRow) - 1u) << 12) | (c1 << 16);
+        }
+        __syncthreads();
+        const uint32_t n_items = (s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]) >> 16;
+        // 3. scatter the points into cell order
+#pragma unroll
+        for (int k = 0; k < kUpdPer; k++) {
+            const uint32_t i = tid + 256u * (uint32_t)k;
+            if (i < n) {
+                const uint32_t pos = s_hist[__float_as_uint(e[k].w) & (kBrickCells - 1)] + rk[k];
+                s_px[pos] = e[k].x;
+                s_py[pos] = e[k].y;
+                s_pz[pos] = e[k].z;
+                if (COLOR) s_rgb[pos] = crgb[k];
+            }
+        }
+        __syncthreads();
+        // 4. rows x dependants
+        for (uint32_t ibase = 0; ibase < n_items; ibase += (uint32_t)kUpdRows) {  // block-uniform trip count
+            const uint32_t ii = ibase + row;
+            const bool rv = ii < n_items;
+            const uint32_t item = rv ? s_item[ii] : 0u;
+            const uint32_t cell = item >> 16;
+            const bool pv = rv && rl <= ((item >> 12) & 15u);
+            const uint32_t pos = (item & 0xFFFu) + rl;
+            F3 p = {0.f, 0.f, 0.f};
+            uint32_t rgb = 0;
+            if (pv) {
+                p = F3{s_px[pos], s_py[pos], s_pz[pos]};
+                if (COLOR) rgb = s_rgb[pos];
+            }
+            const uint32_t cnt = rv ? (uint32_t)s_cnt[cell] : 0u;
+            const uint64_t off = rv ? (uint64_t)s_off[cell] : 0ull;
+            uint32_t max_cnt = cnt;  // wave-uniform trip count: the longest list among the wave's rows
+#pragma unroll
+            for (int o = kUpdRow; o < 64; o <<= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, o));
+            if (pv) c_tested += cnt;
+#if defined(HFPF_ABL) && HFPF_ABL == 1
+            max_cnt = 0;
+#endif
+            for (uint32_t j = 0; j < max_cnt; j++) {
+#ifdef HFPF_ABL
+                if (lane == 0) c_iter++;
+#endif
+                DepEntry en;
+                en.sid = 0;
+                bool mem = false;
+                PairDelta q = {0, 0, 0, 0};
+                if (j < cnt) {
+#if defined(HFPF_ABL) && HFPF_ABL == 3
+                    en.sid = (uint32_t)off + j; en.ax = 0.1f; en.ay = 0.2f; en.az = 0.3f; en.abx = 0.01f; en.aby = 0.02f; en.abz = 0.005f; en.dd = 0.000525f;
+#else
+                    en = t.dep[off + j];  // the same address in every lane of the row
+#endif
+                    if (pv) {
+                        F3 proj;
+                        float sp, distf;
+                        mem = line_member(g, p, F3{en.ax, en.ay, en.az}, F3{en.abx, en.aby, en.abz}, en.dd, sp, proj, distf);
+                        if (mem) q = pair_delta(g, sp, distf);
+                    }
                 }
-            } else {  // table full: straight to HBM
+                const unsigned long long mm = __ballot(mem);
+#if defined(HFPF_ABL) && HFPF_ABL == 2
+                if (mem) c_member += (uint32_t)(q.s + q.ss + q.d + q.dd) & 1u;
+                continue;
+#endif
+                if (mm == 0) continue;  // wave-uniform
+                const uint32_t row_members = (uint32_t)__popcll((mm >> (lane & ~(uint32_t)(kUpdRow - 1))) & ((1ull << kUpdRow) - 1ull));
+                const int sum_s = row_sum(mem ? q.s : 0), sum_ss = row_sum(mem ? q.ss : 0);
+                const int sum_d = row_sum(mem ? q.d : 0), sum_dd = row_sum(mem ? q.dd : 0);
+                int sum_r = 0, sum_g = 0, sum_b = 0;
+                if (COLOR) {
+                    sum_r = row_sum(mem ? (int)((rgb >> 16) & 255u) : 0);
+                    sum_g = row_sum(mem ? (int)((rgb >> 8) & 255u) : 0);
+                    sum_b = row_sum(mem ? (int)(rgb & 255u) : 0);
+                }
+                if (rl == 0 && row_members) {
+                    c_member += row_members;
+                    const unsigned long long add[8] = {(unsigned long long)row_members, (unsigned long long)(long long)sum_s,
+                                                       (unsigned long long)(long long)sum_ss, (unsigned long long)(long long)sum_d,
+                                                       (unsigned long long)(long long)sum_dd, (unsigned long long)(long long)sum_r,
+                                                       (unsigned long long)(long long)sum_g, (unsigned long long)(long long)sum_b};
+                    uint32_t h = upd_hash(en.sid);
+                    bool placed = false;
+                    for (int probe = 0; probe < 16; probe++) {
+                        const uint32_t old = atomicCAS(&keys[h], 0u, en.sid);
+                        if (old == 0u || old == en.sid) {
+                            placed = true;
+                            break;
+                        }
+                        h = (h + 1) & (kUpdSlots - 1);
+                    }
+                    if (placed) {
 #pragma unroll
-                for (int w = 0; w < SW_USED; w++) atomicAdd(&t.stats[(uint64_t)e.sid * kStatWords + w], (unsigned long long)d.v[w]);
-                if constexpr (COLOR) {
-                    atomicAdd(&t.cstats[(uint64_t)e.sid * 4 + 0], (unsigned long long)d.rgb[0]);
-                    atomicAdd(&t.cstats[(uint64_t)e.sid * 4 + 1], (unsigned long long)d.rgb[1]);
-                    atomicAdd(&t.cstats[(uint64_t)e.sid * 4 + 2], (unsigned long long)d.rgb[2]);
+                        for (int w = 0; w < W; w++) atomicAdd(&vals[h * W + w], add[w]);
+                    } else {  // table full: straight to HBM
+#pragma unroll
+                        for (int w = 0; w < W; w++) atomicAdd(&t.stats[(uint64_t)en.sid * kStatWords + w], add[w]);
+                    }
                 }
             }
         }
+        // the next round's barriers keep its scatter behind this round's rows
     }
     __syncthreads();
     {  // flush: 8 lanes per record, 32 records per pass
-        const uint32_t w = threadIdx.x & 7u;
-        for (uint32_t sl = threadIdx.x >> 3; sl < (uint32_t)kUpdSlots; sl += 32) {
+        const uint32_t w = tid & 7u;
+        for (uint32_t sl = tid >> 3; sl < (uint32_t)kUpdSlots; sl += 32) {
             const uint32_t key = keys[sl];
-            if (key != 0u && w < SW_USED) atomicAdd(&t.stats[(uint64_t)key * kStatWords + w], vals[sl * SW_USED + w]);
-            if (COLOR && key != 0u && w < 3) atomicAdd(&t.cstats[(uint64_t)key * 4 + w], cvals[sl * 3 + w]);
+            if (key != 0u && w < (uint32_t)W) atomicAdd(&t.stats[(uint64_t)key * kStatWords + w], vals[sl * W + w]);
         }
     }
 #pragma unroll
@@ -423,14 +588,17 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
         c_tested += __shfl_down(c_tested, o);
         c_member += __shfl_down(c_member, o);
     }
-    if ((threadIdx.x & 63u) == 0) {
+    if (lane == 0) {
         if (c_tested) atomicAdd(&blk_ctr[0], c_tested);
         if (c_member) atomicAdd(&blk_ctr[1], c_member);
     }
     __syncthreads();
     // striped like k_replay's counter: words 2 and 3 of the 64 log_ctr lines, summed by the host
-    if (threadIdx.x < 2 && blk_ctr[threadIdx.x])
-        atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
+    if (tid < 2 && blk_ctr[tid])
+        atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
+#ifdef HFPF_ABL
+    if (lane == 0 && c_iter) atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 4], (unsigned long long)c_iter);
+#endif
 }
 
 // Plan the brick regions of the next launch from the demand of the previous one: cap = demand * scale * 1.25 + 64.
@@ -599,8 +767,17 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
     t.nv_n[3 * nid + 0] = normal.x;
     t.nv_n[3 * nid + 1] = normal.y;
     t.nv_n[3 * nid + 2] = normal.z;
+    {  // the per-voxel half of the cylinder test (grid.hpp:40-49), evaluated once here and copied into dependant entries
+        F3 a, ab;
+        float dd;
+        line_of(g, centre, normal, a, ab, dd);
+        t.nv_line[2 * nid] = make_float4(a.x, a.y, a.z, ab.x);
+        t.nv_line[2 * nid + 1] = make_float4(ab.y, ab.z, dd, 0.f);
+    }
     t.stat_id[slot] = (uint32_t)nid;
     atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 2u);  // normal_found, grid.hpp:398
+    atomicOr(reinterpret_cast<unsigned long long*>(&t.nd_mask[((uint64_t)(slot >> 9) * 8u + ((uint32_t)x & 7u)) * 2]),
+             1ull << ((((uint32_t)y & 7u) << 3) | ((uint32_t)z & 7u)));
 }
 
 // K5: one thread per (new normal, line step).  Occupancy is frozen during a clean pass, so the steps are
@@ -709,13 +886,15 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     while (__ballot(next < cnt) != 0) {
         constexpr int B = HFPF_REPLAY_B;
         uint32_t sid[B];
-        F3 c[B], n[B];
+        F3 la[B], lab[B];
+        float ldd[B];
         int m = 0;
 #pragma unroll
         for (int k = 0; k < B; k++) {
             sid[k] = 0;
-            c[k] = F3{0.f, 0.f, 0.f};
-            n[k] = F3{0.f, 0.f, 1.f};
+            la[k] = F3{0.f, 0.f, 0.f};
+            lab[k] = F3{0.f, 0.f, 1.f};
+            ldd[k] = 1.f;
         }
         while (next < cnt && m < B) {  // gather up to B registrants of this pass
             const DepEntry e = t.dep[off + next];
@@ -725,8 +904,9 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
                 for (int k = 0; k < B; k++)
                     if (k == m) {
                         sid[k] = e.sid;
-                        c[k] = F3{e.cx, e.cy, e.cz};
-                        n[k] = F3{e.nx, e.ny, e.nz};
+                        la[k] = F3{e.ax, e.ay, e.az};
+                        lab[k] = F3{e.abx, e.aby, e.abz};
+                        ldd[k] = e.dd;
                     }
                 m++;
             }
@@ -744,8 +924,8 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
                 for (int k = 0; k < B; k++) {
                     if (k < m) {
                         F3 proj;
-                        double dist;
-                        if (cylinder_member(g, pt, c[k], n[k], proj, dist)) stat_delta_add(d[k], g, proj, c[k], dist, rgb);
+                        float sp, distf;
+                        if (line_member(g, pt, la[k], lab[k], ldd[k], sp, proj, distf)) stat_delta_add(d[k], pair_delta(g, sp, distf), rgb);
                     }
                 }
                 e = __float_as_uint(p.w);  // one 16-byte read per hop: the link travels with the point
@@ -755,7 +935,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         for (int k = 0; k < B; k++) {
             // sum the four sub-chains of the cell (lanes 4i..4i+3) before the flush: one record update per (cell, registrant)
 #pragma unroll
-            for (int w = 0; w < SW_USED; w++) {
+            for (int w = 0; w < kStatUsed; w++) {
                 long long v = d[k].v[w];
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
@@ -789,6 +969,27 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
 }
 
 // ---- dependant table rebuild --------------------------------------------------------------------
+__device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid)
+{
+    const float4 l0 = t.nv_line[2 * (uint64_t)nid], l1 = t.nv_line[2 * (uint64_t)nid + 1];
+    DepEntry e;
+    e.sid = nid;
+    e.ax = l0.x;
+    e.ay = l0.y;
+    e.az = l0.z;
+    e.abx = l0.w;
+    e.aby = l1.x;
+    e.abz = l1.y;
+    e.dd = l1.z;
+    return e;
+}
+// A cell gained its first dependant: set its bit in the brick's flag line (read by k_integrate).
+__device__ __forceinline__ void set_dep_flag(const Tables& t, uint32_t slot)
+{
+    uint64_t plane, bit;
+    slot_plane_bit(slot, plane, bit);
+    atomicOr(reinterpret_cast<unsigned long long*>(&t.nd_mask[plane * 2 + 1]), (unsigned long long)bit);
+}
 __device__ __forceinline__ uint32_t reg_slot(const Tables& t, uint64_t j, uint64_t n_reg) { return j < n_reg ? t.reg_occ[j].x : t.prereg_list[j - n_reg]; }
 
 __global__ __launch_bounds__(256) void k_dep_count(const Tables t, const uint64_t n_reg, const uint64_t n_pre)
@@ -818,6 +1019,7 @@ __global__ __launch_bounds__(256) void k_dep_offsets(const Tables t, const uint6
         cnt = (uint32_t)kDepCntMask;
     }
     t.info[slot] = (t.info[slot] & 3ull) | ((uint64_t)cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
+    if (cnt) set_dep_flag(t, slot);
     t.dep_tmp[slot] = 0;
 }
 
@@ -830,16 +1032,7 @@ __global__ __launch_bounds__(256) void k_dep_fill(const Tables t, const uint64_t
     const uint64_t info = t.info[slot];
     const uint32_t k = atomicAdd(&t.dep_tmp[slot], 1u);
     if (k >= ((info >> kDepCntShift) & kDepCntMask)) return;  // clamped list
-    DepEntry e;
-    e.sid = nid;
-    e.cx = t.nv_c[3 * (uint64_t)nid];
-    e.cy = t.nv_c[3 * (uint64_t)nid + 1];
-    e.cz = t.nv_c[3 * (uint64_t)nid + 2];
-    e.nx = t.nv_n[3 * (uint64_t)nid];
-    e.ny = t.nv_n[3 * (uint64_t)nid + 1];
-    e.nz = t.nv_n[3 * (uint64_t)nid + 2];
-    e.pad = k == 0 ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u;  // the first entry carries the list length
-    t.dep[(info >> kDepOffShift) + k] = e;
+    t.dep[(info >> kDepOffShift) + k] = make_dep_entry(t, nid);
 }
 
 __global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_t n_touched)
@@ -856,19 +1049,6 @@ __global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_
 // fresh space at the end of dep[] and the new entries appended.  The space of the old list is garbage
 // until the next full rebuild (k_dep_count / k_dep_offsets / k_dep_fill), which the host runs when dep[]
 // fills up.
-__device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid, uint32_t list_len_if_first = 0)
-{
-    DepEntry e;
-    e.sid = nid;
-    e.cx = t.nv_c[3 * (uint64_t)nid];
-    e.cy = t.nv_c[3 * (uint64_t)nid + 1];
-    e.cz = t.nv_c[3 * (uint64_t)nid + 2];
-    e.nx = t.nv_n[3 * (uint64_t)nid];
-    e.ny = t.nv_n[3 * (uint64_t)nid + 1];
-    e.nz = t.nv_n[3 * (uint64_t)nid + 2];
-    e.pad = list_len_if_first;  // entry 0 of a list: its length (read by k_update); otherwise unused
-    return e;
-}
 
 __global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg)
 {
@@ -926,12 +1106,9 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
             t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
             continue;
         }
-        for (uint32_t k = 0; k < old_cnt; k++) {
-            DepEntry e = t.dep[old_off + k];
-            if (k == 0) e.pad = new_cnt;  // the first entry carries the list length
-            t.dep[off + k] = e;
-        }
+        for (uint32_t k = 0; k < old_cnt; k++) t.dep[off + k] = t.dep[old_off + k];
         t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
+        if (old_cnt == 0 && new_cnt) set_dep_flag(t, slot);
         t.dep_tmp[slot] = old_cnt;  // append cursor
     }
 }
@@ -945,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
     const uint32_t k = atomicAdd(&t.dep_tmp[r.x], 1u);
     if (k & 0x80000000u) return;
     const uint64_t info = t.info[r.x];
-    t.dep[(info >> kDepOffShift) + k] = make_dep_entry(t, r.y, k == 0 ? (uint32_t)((info >> kDepCntShift) & kDepCntMask) : 0u);
+    t.dep[(info >> kDepOffShift) + k] = make_dep_entry(t, r.y);
 }
 
 // Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).
@@ -985,8 +1162,9 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
                 continue;
             }
             t.info[slot] = (info & 3ull) | (1ull << kDepCntShift) | (off << kDepOffShift);
+            set_dep_flag(t, slot);
         }
-        t.dep[off] = make_dep_entry(t, t.pre_dep[slot], 1u);
+        t.dep[off] = make_dep_entry(t, t.pre_dep[slot]);
     }
 }
 
@@ -1022,8 +1200,7 @@ struct Row {  // = hfpf_row
 static_assert(sizeof(Row) == 64, "row is 64 bytes");
 
 __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const Tables t, const unsigned long long* __restrict__ stats,
-                                                      const unsigned long long* __restrict__ cstats, const uint64_t n_rows,
-                                                      const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                      const uint64_t n_rows, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                       Row* __restrict__ rows)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1043,30 +1220,29 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
         r.mean_dist = r.sd_dist = 0.f;
         r.rgb = 0;
     } else {
+        const float4 l0 = t.nv_line[2 * nid], l1 = t.nv_line[2 * nid + 1];
+        const double ax = l0.x, ay = l0.y, az = l0.z, abx = l0.w, aby = l1.x, abz = l1.y;
         const double inv = 1.0 / (double)cnt;
-        const double mx = ((double)s[SW_S1 + 0] / g.s1_scale) * inv;
-        const double my = ((double)s[SW_S1 + 1] / g.s1_scale) * inv;
-        const double mz = ((double)s[SW_S1 + 2] / g.s1_scale) * inv;
-        r.x = (float)((double)t.nv_c[3 * nid] + mx);
-        r.y = (float)((double)t.nv_c[3 * nid + 1] + my);
-        r.z = (float)((double)t.nv_c[3 * nid + 2] + mz);
-        // projections lie on the voxel's line: per-axis variance = n_i^2 * var(t), var(t) = E|o|^2 - |E o|^2 (stats.hpp)
-        double vt = ((double)s[SW_S2] / g.s2_scale) * inv - ((mx * mx + my * my) + mz * mz);
-        const double md = ((double)s[SW_D] / g.sd_scale) * inv;
-        double vd = ((double)s[SW_DD] / g.sdd_scale) * inv - md * md;
-        if (cnt == 1) vt = vd = 0.0;  // the recurrence gives exactly 0 for a single sample
-        vt = fmax(vt, 0.0);
-        r.sdx = (float)((double)r.nx * (double)r.nx * vt);
-        r.sdy = (float)((double)r.ny * (double)r.ny * vt);
-        r.sdz = (float)((double)r.nz * (double)r.nz * vt);
+        // every projection is a - s*ab (stats.hpp): centroid = a - E[s]*ab, per-axis variance = ab_i^2 * var(s)
+        const double es = ((double)s[SW_S] / (double)g.fs_scale) * inv;
+        r.x = (float)(ax - es * abx);
+        r.y = (float)(ay - es * aby);
+        r.z = (float)(az - es * abz);
+        double vs = ((double)s[SW_SS] / (double)g.fss_scale) * inv - es * es;
+        const double md = ((double)s[SW_D] / (double)g.fd_scale) * inv;
+        double vd = ((double)s[SW_DD] / (double)g.fdd_scale) * inv - md * md;
+        if (cnt == 1) vs = vd = 0.0;  // the recurrence gives exactly 0 for a single sample
+        vs = fmax(vs, 0.0);
+        r.sdx = (float)(abx * abx * vs);
+        r.sdy = (float)(aby * aby * vs);
+        r.sdz = (float)(abz * abz * vs);
         r.mean_dist = (float)md;
         r.sd_dist = (float)fmax(vd, 0.0);
         r.rgb = 0;
-        if (cstats) {
-            const long long* cs = reinterpret_cast<const long long*>(&cstats[nid * 4]);
-            const uint32_t cr = (uint32_t)(((double)cs[0] * inv) + 0.5);
-            const uint32_t cg = (uint32_t)(((double)cs[1] * inv) + 0.5);
-            const uint32_t cb = (uint32_t)(((double)cs[2] * inv) + 0.5);
+        if (t.color) {  // EXTENSION: mean colour of the cylinder members, round half up
+            const uint32_t cr = (uint32_t)((2 * s[SW_R] + cnt) / (2 * cnt));  // exact integer form of floor(sum/cnt + 1/2)
+            const uint32_t cg = (uint32_t)((2 * s[SW_G] + cnt) / (2 * cnt));
+            const uint32_t cb = (uint32_t)((2 * s[SW_B] + cnt) / (2 * cnt));
             r.rgb = (min(cr, 255u) << 16) | (min(cg, 255u) << 8) | min(cb, 255u);
         }
     }

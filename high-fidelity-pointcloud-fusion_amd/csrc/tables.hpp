@@ -17,6 +17,9 @@
 //              dep_tmp u32           scratch for the dependant-table rebuild
 //   per brick: occ_mask[8] u64       occupancy bits, one u64 per x-plane (bit = ly*8+lz): the 5x5x5 stencil
 //                                    of grid.hpp:334-349 becomes <= 20 u64 loads.
+//              nd_mask[8][2] u64     normal_found bits and has-dependants bits, same bit order: one 16-byte read tells
+//                                    k_integrate what to do with a point (22 k bricks x 128 B stay in L2, where the
+//                                    8-byte info words of 10^7 cells do not).
 //   point log: log_pt float4 (x,y,z, w = slot until linked, then `next`) (+ log_rgb u32 with colour fusion): the
 //              reference's per-voxel buffers (grid.hpp:70,211,230) as one append-only array.
 //   normals:   nv_key u64, nv_slot u32, nv_c/nv_n float3, stats[8] i64 per record (stats.hpp)
@@ -82,9 +85,9 @@ enum ErrBits : uint64_t {
 
 struct __attribute__((aligned(32))) DepEntry {  // one dependant of a cell, denormalised for the per-point loop
     uint32_t sid;                               // statistics record to update
-    float cx, cy, cz;                           // its cell centre (getVoxelCenter, grid.hpp:259)
-    float nx, ny, nz;                           // its normal
-    uint32_t pad;
+    float ax, ay, az;                           // a = centre - r*n: one end of the voxel's line segment (geometry.hpp line_of)
+    float abx, aby, abz;                        // ab = a - b
+    float dd;                                   // |ab|^2
 };
 static_assert(sizeof(DepEntry) == 32, "DepEntry must be 32 bytes");
 
@@ -107,8 +110,10 @@ struct Tables {
     uint32_t* nv_slot;
     float* nv_c;  // 3 per record
     float* nv_n;  // 3 per record
+    float4* nv_line;  // 2 per record: (a.xyz, ab.x), (ab.y, ab.z, |ab|^2, 0): the per-voxel half of the cylinder test
     unsigned long long* stats;
-    unsigned long long* cstats;  // optional colour sums, 4 words per record (NULL unless HFPF_FLAG_FUSE_COLOR)
+    uint32_t color;   // 1 with HFPF_FLAG_FUSE_COLOR: words 5-7 of a statistics record carry the members' colour sums
+    uint64_t* nd_mask;  // per brick and x-plane, 2 words: normal_found bits, has-dependants bits of the plane's 64 cells
     uint2* reg_occ;
     DepEntry* dep;
     uint32_t* prereg_list;
@@ -118,7 +123,7 @@ struct Tables {
     float* frame_vp;       // 3 per frame id
     unsigned long long* ctr;
     // brick bins of the two-pass dependant update (kernels.hpp, k_integrate<BIN> + k_update)
-    float4* bin_pt;       // (x, y, z, slot bits) of points parked for k_update, grouped per brick
+    float4* bin_pt;       // (x, y, z, bits of the cell's index inside the brick) of points parked for k_update, grouped per brick
     uint32_t* bin_rgb;    // their colour (HFPF_FLAG_FUSE_COLOR only)
     uint32_t* bin_fill;   // per brick: entries requested in the running launch (may exceed the region)
     uint32_t* bin_off;    // per brick: first entry of its region
@@ -171,6 +176,14 @@ __device__ __forceinline__ void slot_coords(const GridParams& g, const Tables& t
     x = (int32_t)(bx * 8 + compact3(l >> 2));
     y = (int32_t)(by * 8 + compact3(l >> 1));
     z = (int32_t)(bz * 8 + compact3(l));
+}
+
+// Word index into occ_mask (and /2 of nd_mask) and bit of a slot's cell.
+__device__ __forceinline__ void slot_plane_bit(uint32_t slot, uint64_t& plane, uint64_t& bit)
+{
+    const uint32_t l = slot & 511u;
+    plane = (uint64_t)(slot >> 9) * 8u + compact3(l >> 2);
+    bit = 1ull << ((compact3(l >> 1) << 3) | compact3(l));
 }
 
 // Read-only lookup: slot of a cell, inside the null brick (all zeros) when the brick was never touched.

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HFPF_ABI_VERSION 2
+#define HFPF_ABI_VERSION 3
 
 /* hfpf_config.flags */
 #define HFPF_FLAG_FUSE_COLOR 1u /* EXTENSION: also average the member points' RGB per voxel (reference: never, grid.hpp:471-479) */
@@ -206,6 +206,8 @@ int hfpf_dist_disable(hfpf_handle* h);
  * Exported pointers are device memory owned by the handle, valid until its next mutating call. */
 int hfpf_epoch_export(hfpf_handle* h, const void** dev_records, uint64_t* n_records);
 int hfpf_epoch_import(hfpf_handle* h, const void* dev_records, uint64_t n_records);
+/* Since ABI 3 the optional colour sums are words 5-7 of the same 8-word records: *dev_cwords is NULL, *n_cwords 0, and
+ * hfpf_extract_with_stats ignores dev_cwords (both parameters are kept so that ABI-2 callers still link). */
 int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words, const void** dev_cwords, uint64_t* n_cwords);
 int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* dev_cwords, hfpf_row** rows, uint64_t* n_rows);
 int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, uint64_t bytes);
