@@ -36,6 +36,7 @@ struct GridParams {
     int32_t cov_shifted;          // 0: PCL <= 1.10 single-pass moments; 1: PCL >= 1.11 moments of (p - first point)
     // fixed-point scales (powers of two) of the order-free statistic sums, see stats.hpp
     float fs_scale, fss_scale, fd_scale, fdd_scale;
+    float d2_max;  // largest f32 u with (double)sqrtf(u) < cyl_r: membership as one compare on the squared distance
 };
 
 HFPF_HD float sum3(float a, float b, float c) { return a + (b + c); }  // Eigen fixed-size-3 redux: c0 + (c1 + c2)
@@ -123,26 +124,38 @@ HFPF_HD void line_of(const GridParams& g, F3 centre, F3 n, F3& a, F3& ab, float&
     dd = dot3(ab, ab);
 }
 
-// s = the projection parameter (proj = a - s*ab, so s = 0.5 at the cell centre); distf = ||pt - proj|| in f32.
-HFPF_HD bool line_member(const GridParams& g, F3 pt, F3 a, F3 ab, float dd, float& s, F3& proj, float& distf)
+// s = the projection parameter (proj = a - s*ab, so s = 0.5 at the cell centre); d2 = ||pt - proj||^2 in f32.
+HFPF_HD void line_project(F3 pt, F3 a, F3 ab, float dd, float& s, F3& proj, float& d2)
 {
     const F3 ap = sub3(a, pt);
     s = dot3(ap, ab) / dd;
     proj = sub3(a, mul3(s, ab));
     const F3 df = sub3(pt, proj);
-    distf = sqrtf(dot3(df, df));
-    return (double)distf < g.cyl_r;
+    d2 = dot3(df, df);
 }
 
 // The reference's form (used by the leaf probes): returns membership; proj and dist are outputs.
 HFPF_HD bool cylinder_member(const GridParams& g, F3 pt, F3 centre, F3 n, F3& proj, double& dist)
 {
     F3 a, ab;
-    float dd, s, distf;
+    float dd, s, d2;
     line_of(g, centre, n, a, ab, dd);
-    const bool m = line_member(g, pt, a, ab, dd, s, proj, distf);
-    dist = (double)distf;
-    return m;
+    line_project(pt, a, ab, dd, s, proj, d2);
+    dist = (double)sqrtf(d2);  // Eigen norm(): correctly rounded f32 sqrt, widened (grid.hpp:261)
+    return dist < g.cyl_r;
+}
+
+// The kernels' form.  Membership is decided on the squared distance: a correctly rounded sqrt is monotonic, so
+// (double)sqrtf(d2) < cyl_r  <=>  d2 <= d2_max with d2_max the largest f32 that passes (found by the host at create and
+// checked against the form above by the leaf tests) -- identical decisions without the IEEE sqrt refinement and the f64 compare.
+// distf, which only feeds the mean_dist / sd_dist sums, comes from the 1-ulp hardware sqrt.
+__device__ __forceinline__ bool line_member(const GridParams& g, F3 pt, F3 a, F3 ab, float dd, float& s, float& distf)
+{
+    F3 proj;
+    float d2;
+    line_project(pt, a, ab, dd, s, proj, d2);
+    distf = __builtin_amdgcn_sqrtf(d2);
+    return d2 <= g.d2_max;
 }
 
 // ---- plane fit: pcl::computeMeanAndCovarianceMatrix + pcl::eigen33 (call sites grid.hpp:302,289) ----

@@ -203,11 +203,16 @@ int read_counters(hfpf_handle* h)
         upd_tested += h->h_log_ctr[r * 16 + 2];
         upd_member += h->h_log_ctr[r * 16 + 3];
     }
-#ifdef HFPF_ABL
-    {
-        unsigned long long it = 0;
-        for (int r = 0; r < kLogRegions; r++) it += h->h_log_ctr[r * 16 + 4];
-        if (getenv("HFPF_ABL_PRINT")) fprintf(stderr, "[abl] k_update wave-iterations %llu, pairs tested %llu, lane utilisation %.3f\n", it, upd_tested, it ? (double)upd_tested / (64.0 * (double)it) : 0.0);
+#ifdef HFPF_STAMP
+    if (getenv("HFPF_STAMP_PRINT")) {
+        unsigned long long acc[9] = {0};
+        for (int r = 0; r < kLogRegions; r++)
+            for (int k = 0; k < 9; k++) acc[k] += h->h_log_ctr[r * 16 + 5 + k];
+        if (acc[8]) {
+            fprintf(stderr, "[stamp] k_update, %llu bricks, mean cycles per brick by phase (info+scan, load+rank, items, scatter, stage+zero, rows, flush, tail):", acc[8]);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", (double)acc[k] / (double)acc[8]);
+            fprintf(stderr, "\n");
+        }
     }
 #endif
     h->h_ctr[C_DEP_TESTED] += upd_tested;
@@ -271,6 +276,17 @@ int setup_params(hfpf_handle* h)
     g.fss_scale = stat_scale_for(Bs * Bs);
     g.fd_scale = stat_scale_for(g.cyl_r);
     g.fdd_scale = stat_scale_for(g.cyl_r * g.cyl_r);
+    {   // largest f32 u with (double)sqrtf(u) < cyl_r (sqrtf is correctly rounded on the host: IEEE 754), by bisection on the bits
+        uint32_t lo_b = 0, hi_b = 0x7F800000u;  // invariant: f(lo) passes, f(hi) fails (sqrt(+inf) = inf)
+        while (hi_b - lo_b > 1) {
+            const uint32_t mid = lo_b + (hi_b - lo_b) / 2;
+            float u;
+            memcpy(&u, &mid, 4);
+            if ((double)sqrtf(u) < g.cyl_r) lo_b = mid;
+            else hi_b = mid;
+        }
+        memcpy(&g.d2_max, &lo_b, 4);
+    }
     const double dir_entries = (double)g.bdim[0] * (double)g.bdim[1] * (double)g.bdim[2];
     if (dir_entries > 4.0e9) return fail(h, HFPF_ERR_BAD_CONFIG, "brick directory too large (%.3g entries)", dir_entries);
     h->dir_entries = (size_t)dir_entries;
@@ -527,8 +543,8 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, true);
         else HFPF_LAUNCH_INTEGRATE(false, true, true);
         if (nb > 0 && h->bin_have_hist && !demand_only) {
-            if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
-            else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
+            if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
+            else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
         }
         h->bin_have_hist = true;
         h->bin_prev_points = (double)n_points * n_frames;

@@ -413,7 +413,10 @@ class OccupancyGrid:
         dist = np.zeros(n, np.float64)
         member = np.zeros(n, np.uint8)
         self._chk(lib().hfpf_probe_project(self._h, n, _p(pts), _p(centres), _p(normals), _p(proj), _p(dist), _p(member)))
-        return proj, dist, member.astype(bool)
+        # bit 0: the reference's form (f32 sqrt widened, compared with the radius); bit 1: the kernels' form (squared
+        # distance against the precomputed largest passing value) -- kept for the test that the two always agree
+        self.last_member_kernel_form = (member & 2) != 0
+        return proj, dist, (member & 1) != 0
 
     def probe_trig(self, y, x):
         y = np.ascontiguousarray(y, dtype=np.float32)

@@ -248,6 +248,10 @@ struct VoxelInfo {
     std::vector<uint64_t> dependants;
     bool normal_found = false;
     int count = 0;
+    // EXTENSION (not in the reference, which drops colour at grid.hpp:196-197): with Config::fuse_color the
+    // buffered points keep their packed rgb and every cylinder member adds its r, g, b to the voxel it updates.
+    std::vector<uint32_t> buffer_rgb;
+    uint64_t csum[3] = {0, 0, 0};
 };
 
 struct Voxel {
@@ -278,6 +282,7 @@ struct Config {  // mirrored by oracle.py
     int32_t order_mode;      // 0 canonical ascending (x,y,z); 1 libstdc++ unordered_set order
     int32_t reserve;         // buffer.reserve(n) on first touch (reference: 1000, grid.hpp:228); 0 = off
     int32_t pcl_shifted_cov; // 0 = PCL <= 1.10 computeMeanAndCovarianceMatrix (default), 1 = PCL >= 1.11 shifted form
+    int32_t fuse_color;      // EXTENSION: 1 = per-voxel mean colour of the cylinder members (definition in extract())
 };
 
 class Oracle {
@@ -392,9 +397,18 @@ public:
                                                       (double)d->count);
     }
 
-    // grid.hpp:185-280 addPoints<N>(cloud, viewpoint).  Points are already in the fusion frame.
-    void add_points(const V3* pts, size_t n, const V3& viewpoint)
+    static void add_color(VoxelInfo* d, uint32_t rgb)  // packed 0x00RRGGBB; blue with shift 0 (not the reference's shift 1, node.cpp:174)
     {
+        d->csum[0] += (rgb >> 16) & 255u;
+        d->csum[1] += (rgb >> 8) & 255u;
+        d->csum[2] += rgb & 255u;
+    }
+
+    // grid.hpp:185-280 addPoints<N>(cloud, viewpoint).  Points are already in the fusion frame.
+    // rgb (optional, colour extension): the points' packed colours.
+    void add_points(const V3* pts, size_t n, const V3& viewpoint, const uint32_t* rgb = nullptr)
+    {
+        const bool color = cfg.fuse_color != 0 && rgb != nullptr;
         state_changed = true;
         for (size_t p = 0; p < n; p++) {
             const V3 point = pts[p];
@@ -408,9 +422,10 @@ public:
             const V3 ptv = point;
             if (voxel.occupied) {
                 VoxelInfo* data = voxel.data;
-                if (!data->normal_found)
+                if (!data->normal_found) {
                     data->buffer.push_back(ptv);
-                else {
+                    if (color) data->buffer_rgb.push_back(rgb[p]);
+                } else {
                     if (unprocessed_.find(hash) != unprocessed_.end()) unprocessed_.erase(hash);
                 }
             } else {
@@ -421,12 +436,14 @@ public:
                     if (cfg.reserve > 0) data->buffer.reserve((size_t)cfg.reserve);
                     data->viewpoint = viewpoint;
                     data->buffer.push_back(ptv);
+                    if (color) data->buffer_rgb.push_back(rgb[p]);
                     voxel.data = data;
                 } else {
                     VoxelInfo* data = voxel.data;  // block attached by a clean pass, grid.hpp:234-241
                     if (cfg.reserve > 0) data->buffer.reserve((size_t)cfg.reserve);
                     data->viewpoint = viewpoint;
                     data->buffer.push_back(ptv);
+                    if (color) data->buffer_rgb.push_back(rgb[p]);
                 }
             }
             // grid.hpp:244-277 dependant updates
@@ -439,7 +456,10 @@ public:
                 V3 dep_centre = voxel_center(xx, yy, zz);
                 V3 proj = project_point_to_vector(ptv, dep_centre, dep->normal, ball_r_f);
                 double distance_to_normal = (double)norm3(sub3(ptv, proj));
-                if (distance_to_normal < cfg.cylinder_radius) welford(dep, proj, distance_to_normal);
+                if (distance_to_normal < cfg.cylinder_radius) {
+                    welford(dep, proj, distance_to_normal);
+                    if (color) add_color(dep, rgb[p]);
+                }
             }
         }
     }
@@ -448,9 +468,11 @@ public:
     // node.cpp:289 transformPointCloud(Affine3d), node.cpp:290 viewpoint, then addPoints.
     // `n` must already be row_step/point_step (first-row rule, node.cpp:185,190).
     void capture(const uint8_t* base, size_t n, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
-                 const double* T /* 3x4 row-major */)
+                 const double* T /* 3x4 row-major */, uint32_t off_rgb = 0xFFFFFFFFu)
     {
         std::vector<V3> out;
+        std::vector<uint32_t> out_rgb;
+        const bool color = cfg.fuse_color != 0 && off_rgb != 0xFFFFFFFFu;
         out.reserve(n);
         for (size_t i = 0; i < n; i++) {
             const uint8_t* rec = base + i * (size_t)point_step;
@@ -466,9 +488,14 @@ public:
             q.y = (float)(T[4] * (double)x + T[5] * (double)y + T[6] * (double)z + T[7]);
             q.z = (float)(T[8] * (double)x + T[9] * (double)y + T[10] * (double)z + T[11]);
             out.push_back(q);
+            if (color) {
+                uint32_t c;
+                memcpy(&c, rec + off_rgb, 4);
+                out_rgb.push_back(c);
+            }
         }
         V3 vp = {(float)T[3], (float)T[7], (float)T[11]};
-        add_points(out.data(), out.size(), vp);
+        add_points(out.data(), out.size(), vp, color ? out_rgb.data() : nullptr);
     }
 
     // grid.hpp:311-454 updateThicknessVectors<N,K>
@@ -542,7 +569,10 @@ public:
                             const V3 pt = nd_->buffer[b];
                             V3 proj = project_point_to_vector(pt, centroid, data->normal, ball_r_f);
                             double distance_to_normal = (double)norm3(sub3(pt, proj));
-                            if (distance_to_normal < cfg.cylinder_radius) welford(data, proj, distance_to_normal);
+                            if (distance_to_normal < cfg.cylinder_radius) {
+                                welford(data, proj, distance_to_normal);
+                                if (cfg.fuse_color && b < nd_->buffer_rgb.size()) add_color(data, nd_->buffer_rgb[b]);
+                            }
                         }
                     } else {
                         // grid.hpp:443-449: overwrites any previous dependants-only block (leak in the reference)
@@ -586,6 +616,14 @@ public:
             r.mean_dist = d->mean_dist;
             r.sd_dist = d->sd_dist;
             r.rgb = 0;  // never written by the reference (grid.hpp:471-479)
+            if (cfg.fuse_color && d->count > 0) {
+                // EXTENSION: mean colour of the cylinder members per channel, round half up: floor(sum / count + 1/2)
+                const uint64_t n2 = 2ull * (uint64_t)d->count;
+                const uint32_t cr = (uint32_t)((2 * d->csum[0] + (uint64_t)d->count) / n2);
+                const uint32_t cg = (uint32_t)((2 * d->csum[1] + (uint64_t)d->count) / n2);
+                const uint32_t cb = (uint32_t)((2 * d->csum[2] + (uint64_t)d->count) / n2);
+                r.rgb = (std::min(cr, 255u) << 16) | (std::min(cg, 255u) << 8) | std::min(cb, 255u);
+            }
         }
     }
 
@@ -879,6 +917,11 @@ void horacle_capture(void* h, const void* base, uint64_t n, uint32_t point_step,
                      uint32_t off_z, const double* pose)
 {
     ((Oracle*)h)->capture((const uint8_t*)base, n, point_step, off_x, off_y, off_z, pose);
+}
+void horacle_capture_rgb(void* h, const void* base, uint64_t n, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                         uint32_t off_z, uint32_t off_rgb, const double* pose)
+{
+    ((Oracle*)h)->capture((const uint8_t*)base, n, point_step, off_x, off_y, off_z, pose, off_rgb);
 }
 void horacle_add_points(void* h, const float* xyz, uint64_t n, const float* vp)
 {

@@ -27,6 +27,7 @@ class Config(C.Structure):
         ("order_mode", C.c_int32),
         ("reserve", C.c_int32),
         ("pcl_shifted_cov", C.c_int32),
+        ("fuse_color", C.c_int32),
     ]
 
 
@@ -62,6 +63,8 @@ def lib():
         L.horacle_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.horacle_capture.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_void_p]
+        L.horacle_capture_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.c_void_p]
         L.horacle_add_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.horacle_clean.argtypes = [C.c_void_p]
         L.horacle_capture_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -104,7 +107,7 @@ def _p(a):
 
 
 def make_config(resolution=0.005, bbox=(-0.8, 1.8, -1.5, 1.5, 0.0, 1.0), k=2, K=3, gate=20, cylinder_radius=0.001,
-                ball_radius=0.015, z_clip=(0.28, 0.6), order_mode=0, reserve=0, pcl_shifted_cov=False):
+                ball_radius=0.015, z_clip=(0.28, 0.6), order_mode=0, reserve=0, pcl_shifted_cov=False, fuse_color=False):
     """Defaults are the reference's constants (node.cpp:91-93,163,311; grid.hpp:34-36,352; launch:7)."""
     c = Config()
     c.resolution = resolution
@@ -115,6 +118,7 @@ def make_config(resolution=0.005, bbox=(-0.8, 1.8, -1.5, 1.5, 0.0, 1.0), k=2, K=
     c.z_clip_min, c.z_clip_max = z_clip
     c.order_mode, c.reserve = order_mode, reserve
     c.pcl_shifted_cov = 1 if pcl_shifted_cov else 0
+    c.fuse_color = 1 if fuse_color else 0  # EXTENSION (not in the reference): mean colour of the cylinder members
     return c
 
 
@@ -148,13 +152,17 @@ class OracleGrid:
         lib().horacle_dims(self._h, d, C.byref(r))
         return (d[0], d[1], d[2]), r.value
 
-    def capture(self, buf, pose, n_points=None, point_step=16, off_x=0, off_y=4, off_z=8):
-        """buf: contiguous uint8/any ndarray holding PointCloud2-style records; pose: 3x4 f64."""
+    def capture(self, buf, pose, n_points=None, point_step=16, off_x=0, off_y=4, off_z=8, off_rgb=None):
+        """buf: contiguous uint8/any ndarray holding PointCloud2-style records; pose: 3x4 f64.  off_rgb: offset of the packed
+        rgb field, read only by the colour extension (fuse_color=True)."""
         buf = np.ascontiguousarray(buf)
         pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
         if n_points is None:
             n_points = buf.nbytes // point_step
-        lib().horacle_capture(self._h, _p(buf), n_points, point_step, off_x, off_y, off_z, _p(pose))
+        if off_rgb is None:
+            lib().horacle_capture(self._h, _p(buf), n_points, point_step, off_x, off_y, off_z, _p(pose))
+        else:
+            lib().horacle_capture_rgb(self._h, _p(buf), n_points, point_step, off_x, off_y, off_z, off_rgb, _p(pose))
 
     # All-cores timing baseline: own sharded voxel store, float results not run-to-run reproducible.  Never mix with
     # capture()/clean() on one grid and never use it as a parity checker.

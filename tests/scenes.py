@@ -32,14 +32,15 @@ class Scene:
         yield ("clean",)
 
 
-def run(grid, scene, capture_name):
-    """Drive an oracle grid (capture) or an engine grid (integrate) through the scene's schedule."""
+def run(grid, scene, capture_name, color=False):
+    """Drive an oracle grid (capture) or an engine grid (integrate) through the scene's schedule.  color=True also hands
+    the oracle the rgb field (its colour extension, fuse_color=True)."""
     lay = scene.layout
     for ev in scene.schedule():
         if ev[0] == "integrate":
             buf = scene.frame(ev[1])
             kw = dict(point_step=lay["point_step"], off_x=lay["off_x"], off_y=lay["off_y"], off_z=lay["off_z"])
-            if capture_name == "integrate":
+            if capture_name == "integrate" or color:
                 kw["off_rgb"] = lay["off_rgb"]
             getattr(grid, capture_name)(buf, scene.poses[ev[1]], **kw)
         else:
@@ -69,6 +70,8 @@ def compare_rows(ref, got, normals_exact=True):
         assert np.array_equal(ref[f], got[f]), "voxel index column %s differs" % f
     assert np.array_equal(ref["count"], got["count"]), "points-in-cylinder counts differ at %d rows" % int(
         np.sum(ref["count"] != got["count"]))
+    # 0 everywhere as in the reference, or (colour extension on both sides) the members' mean colour, rounded half up: integer work
+    assert np.array_equal(ref["rgb"], got["rgb"]), "rgb differs at %d rows" % int(np.sum(ref["rgb"] != got["rgb"]))
     for f in ("nx", "ny", "nz"):
         if normals_exact:
             assert np.array_equal(ref[f].view(np.uint32), got[f].view(np.uint32)), "normal %s not bit-identical" % f

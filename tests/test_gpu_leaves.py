@@ -94,10 +94,15 @@ def test_projection_membership_bit_exact(oracle_mod, hfpf_mod):
     proj_ref, dist_ref = oracle_mod.probe_project(p, c, nn)
     with hfpf_mod.OccupancyGrid(**TINY) as g:
         proj, dist, member = g.probe_project(p, c, nn)
+        member_kernel = g.last_member_kernel_form
     assert np.array_equal(_bits(proj), _bits(proj_ref))
     assert np.array_equal(dist, dist_ref)
     assert np.array_equal(member, dist_ref < 0.001)
     assert 0.2 < member.mean() < 0.8  # the boundary really is exercised on both sides
+    # the kernels decide membership on the squared distance (d2 <= largest f32 whose correctly rounded sqrt passes): same decisions
+    assert np.array_equal(member_kernel, member)
+    near = np.abs(dist_ref - 0.001) < 1e-9  # a few ulps of the f32 distance around the radius
+    assert near.sum() > 20 and np.array_equal(member_kernel[near], member[near])
 
 
 def test_plane_fit_bit_exact(oracle_mod, hfpf_mod):

@@ -63,13 +63,15 @@ def test_virtual_ranks_viewpoint_latch_is_global_min(hfpf_mod, synth_mod):
     assert rows.tobytes() == single.tobytes()
 
 
-def test_virtual_ranks_with_colour(hfpf_mod, synth_mod):
+def test_virtual_ranks_with_colour(oracle_mod, hfpf_mod, synth_mod):
     sc = scenes.Scene(4, 160, 120, 0.001, fx=615.0, clean_every=2)
     with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, fuse_color=True, **SMALL) as one:
         single = scenes.run(one, sc, "integrate")
     rows, _, _ = _run_virtual(hfpf_mod, sc, 2, fuse_color=True)
     assert rows.tobytes() == single.tobytes()
     assert (rows["rgb"][rows["count"] > 0] != 0).any()
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox, fuse_color=True)
+    scenes.compare_rows(scenes.run(og, sc, "capture", color=True), rows)  # colour sums merge exactly across ranks
 
 
 def test_rccl_path_world_size_one(hfpf_mod, synth_mod):

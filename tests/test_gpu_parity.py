@@ -93,9 +93,12 @@ def test_capacity_overflow_is_reported(hfpf_mod, synth_mod):
         assert e.value.code == -3 and "brick" in str(e.value)
 
 
-def test_colour_extension_does_not_change_geometry(hfpf_mod, synth_mod):
-    """HFPF_FLAG_FUSE_COLOR (extension; the reference never fuses colour): same rows, plus the member points' mean RGB."""
+def test_colour_extension_does_not_change_geometry(oracle_mod, hfpf_mod, synth_mod):
+    """HFPF_FLAG_FUSE_COLOR (extension; the reference never fuses colour): same rows, plus the member points' mean RGB,
+    bit-exact against the oracle's definition of the extension (sum of the members' r, g, b over count, round half up)."""
     sc = scenes.Scene(5, 160, 120, 0.001, fx=615.0, clean_every=2)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox, fuse_color=True)
+    ref = scenes.run(og, sc, "capture", color=True)
     with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as a:
         ra = scenes.run(a, sc, "integrate")
     with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, fuse_color=True, **SMALL) as b:
@@ -105,9 +108,14 @@ def test_colour_extension_does_not_change_geometry(hfpf_mod, synth_mod):
         if f != "rgb":
             assert np.array_equal(ra[f], rb[f]), f
     assert (rb["rgb"][rb["count"] == 0] == 0).all()
-    has = rb["count"] > 3
-    r = (rb["rgb"][has] >> 16) & 255
-    assert 60 < r.mean() < 195  # mean of hash colours sits mid-range
+    scenes.compare_rows(ref, rb)  # includes rgb, bit-exact
+    has = rb["count"] > 0
+    assert has.sum() > 1000 and len(np.unique(rb["rgb"][has])) > 1000  # real colours, not a constant
+    # PCL32 layout (rgb at offset 16) reads the same colours
+    sc32 = scenes.Scene(5, 160, 120, 0.001, fx=615.0, clean_every=2, layout=synth_mod.LAYOUT_PCL32)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, fuse_color=True, **SMALL) as c:
+        rc = scenes.run(c, sc32, "integrate")
+    assert rc.tobytes() == rb.tobytes()
 
 
 def test_clear_then_rerun_is_identical(hfpf_mod, synth_mod):
