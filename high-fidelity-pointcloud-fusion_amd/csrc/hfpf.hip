@@ -203,18 +203,6 @@ int read_counters(hfpf_handle* h)
         upd_tested += h->h_log_ctr[r * 16 + 2];
         upd_member += h->h_log_ctr[r * 16 + 3];
     }
-#ifdef HFPF_STAMP
-    if (getenv("HFPF_STAMP_PRINT")) {
-        unsigned long long acc[9] = {0};
-        for (int r = 0; r < kLogRegions; r++)
-            for (int k = 0; k < 9; k++) acc[k] += h->h_log_ctr[r * 16 + 5 + k];
-        if (acc[8]) {
-            fprintf(stderr, "[stamp] k_update, %llu bricks, mean cycles per brick by phase (info+scan, load+rank, items, scatter, stage+zero, rows, flush, tail):", acc[8]);
-            for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", (double)acc[k] / (double)acc[8]);
-            fprintf(stderr, "\n");
-        }
-    }
-#endif
     h->h_ctr[C_DEP_TESTED] += upd_tested;
     h->h_ctr[C_DEP_MEMBER] += upd_member;
     h->n_bricks_known = std::min<uint64_t>(h->h_ctr[C_BRICKS], h->t.max_bricks);

@@ -342,336 +342,116 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 
 
 // ------------------------------------------------------------------------------------------------
-// K2 (binned form): one workgroup (512 threads, thread t <-> cell t of the brick) per brick.
-//
-//   1. The brick's parked points are read back coalesced and counting-sorted by cell in LDS (one returning LDS atomic per
-//      point gives its rank inside the cell; a 512-entry scan gives the cells' runs), kUpdCap points per round.
-//   2. A "row" of kUpdRow lanes takes up to kUpdRow points of ONE cell.  Every lane of a row walks the same dependant list,
-//      staged in LDS once per brick: a dependant entry is one broadcast LDS read per row.  (The per-lane form -- each lane
-//      walking its own list in global memory -- was bound by the vector L1's access rate, 64 different lines per load
-//      instruction; with per-lane lists in LDS it is bound by the LDS atomics instead.)
-//   3. The members' contributions (four integers < 2^27, stats.hpp) are summed across the row with DPP adds in 32 bits;
-//      the row's first lane adds the row sum to an LDS table indexed by the entry's position -- kUpdRow times fewer LDS
-//      atomics, no hashing, no probing.
-//   4. The table is flushed with 8 lanes per entry: one 64-byte memory-side request per (cell, dependant) per brick and
-//      launch.  Bricks with more than kUpdEnt dependant entries take the steps 2-4 in groups of kUpdEnt entries.
-#ifndef HFPF_UPD_ROW
-#define HFPF_UPD_ROW 8   // lanes per row (8 or 16)
+// K2 (binned form): one workgroup per brick.  The brick's parked points are read back coalesced; a point finds its cell's
+// dependant list through the brick's 512 info words (staged in LDS: k_integrate no longer reads them), and every
+// (point, dependant) member pair adds its contribution (stats.hpp) to an LDS table keyed by record id (open addressing,
+// LDS atomics).  The table is flushed with 8 lanes per record, so a record costs one 64-byte memory-side request per
+// brick per launch however many of the brick's cells and points touched it.  A full table falls back to direct device
+// atomics.  Tried instead and slower on the bench: points counting-sorted by cell in LDS with
+// rows of lanes sharing a list (1.3 ms against 1.0: the sort, the row reductions and the barriers cost more than the
+// broadcast reads save) and lists staged in LDS with a table indexed by list position (1.35 ms: 3.7x the flushes).
+#ifndef HFPF_UPD_BITS
+#define HFPF_UPD_BITS 9  // log2 of the LDS table size of k_update
 #endif
-#ifndef HFPF_UPD_PER
-#define HFPF_UPD_PER 4   // points a thread holds in registers while a round is sorted
-#endif
-#ifndef HFPF_UPD_ENT
-#define HFPF_UPD_ENT 512  // dependant entries staged per group
-#endif
-constexpr int kUpdEnt0 = HFPF_UPD_ENT;
-constexpr int kUpdThreads = 512;
-constexpr int kUpdWaves = kUpdThreads / 64;
-constexpr int kUpdRow = HFPF_UPD_ROW;
-constexpr int kUpdPer = HFPF_UPD_PER;
-constexpr int kUpdCap = kUpdThreads * kUpdPer;          // points sorted per round
-constexpr int kUpdRows = kUpdThreads / kUpdRow;         // rows per workgroup
-constexpr int kUpdItems = kUpdCap / kUpdRow + kBrickCells;  // (cell, up-to-kUpdRow points) work items per round, worst case
-constexpr int kUpdMaxList = 64;                         // longest list that is staged (a longer one takes the global path)
-static_assert(kUpdThreads == kBrickCells, "thread t owns cell t");
-static_assert(kUpdRow == 4 || kUpdRow == 8 || kUpdRow == 16, "row width");
-static_assert(kUpdCap <= 4096, "item encoding holds 12 bits of start");
-
-// Sum over the lanes of a row (every lane receives the sum).  DPP: quad_perm xor 1, xor 2, then across the quads.
-template <int CTRL>
-__device__ __forceinline__ int dpp_get(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-__device__ __forceinline__ int row_sum(int v)
-{
-    v += dpp_get<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_get<0x4E>(v);   // quad_perm [2,3,0,1]
-    if (kUpdRow == 4) return v;
-    if (kUpdRow == 16) {
-        v += dpp_get<0x124>(v);  // row_ror:4
-        v += dpp_get<0x128>(v);  // row_ror:8
-    } else {
-        v += dpp_get<0x141>(v);  // row_half_mirror: lane i <-> 7-i of each 8-lane half
-    }
-    return v;
-}
-
-// Exclusive scan of one value per thread over the 512 threads of the workgroup; *total = sum.  Contains one barrier;
-// `wsum` (kUpdWaves words) must not be reused before the next barrier.
-__device__ __forceinline__ uint32_t upd_block_scan(uint32_t v, uint32_t* wsum, uint32_t& total)
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(incl, o);
-        if (lane >= (uint32_t)o) incl += u;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < (uint32_t)kUpdWaves; w++) {
-        const uint32_t x = wsum[w];
-        if (w < wave) before += x;
-        total += x;
-    }
-    return before + incl - v;
-}
+constexpr int kUpdSlots = 1 << HFPF_UPD_BITS;
+constexpr int kUpdThreads = 256;
+__device__ __forceinline__ uint32_t upd_hash(uint32_t sid) { return (sid * 2654435761u) >> (32 - HFPF_UPD_BITS); }
 
 template <bool COLOR>
-__global__ __launch_bounds__(512) void k_update(const GridParams g, const Tables t, const uint32_t n_bricks)
+__global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables t, const uint32_t n_bricks)
 {
     constexpr int W = COLOR ? 8 : kStatUsed;
-    constexpr int ENT = COLOR ? kUpdEnt0 / 2 : kUpdEnt0;   // entries per group
-    constexpr int ENT_ALLOC = ENT + kUpdMaxList;           // a list that starts inside a group may run past its end
-    __shared__ uint32_t s_hist[kBrickCells];  // points per cell, then first sorted position of the cell's run
-    __shared__ uint16_t s_cnt[kBrickCells];   // dependants per cell
-    __shared__ uint32_t s_off[kBrickCells];   // start of the cell's dependant list in dep[]
-    __shared__ uint32_t s_eb[kBrickCells];    // exclusive prefix of s_cnt: the cell's first entry in the brick's entry sequence
-    __shared__ float s_px[kUpdCap], s_py[kUpdCap], s_pz[kUpdCap];
-    __shared__ uint32_t s_rgb[COLOR ? kUpdCap : 1];
-    __shared__ uint32_t s_item[kUpdItems];    // start | (points - 1) << 12 | cell << 16, ordered by the cell's list length
-    __shared__ uint32_t s_cls[kUpdMaxList + 1];  // items per list length, then the first item of each length class
-    __shared__ float4 s_ent[ENT_ALLOC * 2];
-    __shared__ unsigned long long s_val[ENT_ALLOC * W];
-    __shared__ uint32_t s_wsum[2][kUpdWaves];
+    __shared__ uint64_t s_info[kBrickCells];
+    __shared__ uint32_t keys[kUpdSlots];
+    __shared__ unsigned long long vals[kUpdSlots * W];
     __shared__ unsigned int blk_ctr[2];
     const uint32_t b = blockIdx.x + 1;
     if (b > n_bricks) return;
     const uint32_t fill = min(t.bin_fill[b], t.bin_capb[b]);
     if (fill == 0) return;  // block-uniform
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x;
     const uint64_t first = t.bin_off[b];
-#ifdef HFPF_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
-#define HFPF_ST(k)                                                        \
-    do {                                                                  \
-        const unsigned long long st_now = __builtin_amdgcn_s_memtime();   \
-        st_acc[k] += st_now - st_prev;                                    \
-        st_prev = st_now;                                                 \
-    } while (0)
-#else
-#define HFPF_ST(k) do { } while (0)
-#endif
-    // thread t owns cell t: list length, list offset, position in the brick's entry sequence
-    uint32_t my_cnt, my_off, my_eb, n_ent;
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < fill) pe = t.bin_pt[first + tid];  // in flight while the tables are set up
     {
-        const uint64_t info = t.info[(uint64_t)b * kBrickCells + tid];
-        my_cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-        my_off = (uint32_t)(info >> kDepOffShift);  // < 2^32, checked at create
+        const ulonglong2 inf = *reinterpret_cast<const ulonglong2*>(&t.info[(uint64_t)b * kBrickCells + 2u * tid]);
+        for (uint32_t i = tid; i < (uint32_t)kUpdSlots; i += 256) keys[i] = 0;
+        for (uint32_t i = tid; i < (uint32_t)(kUpdSlots * W); i += 256) vals[i] = 0;
         if (tid < 2) blk_ctr[tid] = 0;
-        my_eb = upd_block_scan(my_cnt, s_wsum[1], n_ent);
-        s_cnt[tid] = (uint16_t)my_cnt;
-        s_off[tid] = my_off;
-        s_eb[tid] = my_eb;
+        s_info[2u * tid] = inf.x;
+        s_info[2u * tid + 1] = inf.y;
     }
-    const bool my_staged = my_cnt > 0 && my_cnt <= (uint32_t)kUpdMaxList;
-    const bool any_long = __syncthreads_or(my_cnt > (uint32_t)kUpdMaxList) != 0;  // pathological: a list too long to stage
-    HFPF_ST(0);
-    uint32_t c_tested = 0, c_member = 0;
-    const uint32_t row = tid / kUpdRow, rl = tid % kUpdRow;
+    __syncthreads();
     const float4* __restrict__ dep4 = reinterpret_cast<const float4*>(t.dep);
-
-    for (uint32_t chunk = 0; chunk < fill; chunk += (uint32_t)kUpdCap) {  // block-uniform trip count
-        const uint32_t n = min((uint32_t)kUpdCap, fill - chunk);
-        s_hist[tid] = 0;
-        __syncthreads();
-        // 1. read the round's points, rank each inside its cell
-        float4 e[kUpdPer];
-        uint32_t rk[kUpdPer], crgb[COLOR ? kUpdPer : 1];
-#pragma unroll
-        for (int k = 0; k < kUpdPer; k++) {
-            const uint32_t i = tid + (uint32_t)kUpdThreads * (uint32_t)k;
-            e[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rk[k] = 0;
-            if (i < n) {
-                e[k] = t.bin_pt[first + chunk + i];
-                if (COLOR) crgb[k] = t.bin_rgb[first + chunk + i];
-            }
+    uint32_t c_tested = 0, c_member = 0;
+    for (uint32_t i = tid; i < fill; i += 256) {
+        const float4 cur = pe;
+        const uint32_t rgb = COLOR ? t.bin_rgb[first + i] : 0u;
+        if (i + 256 < fill) pe = t.bin_pt[first + i + 256];  // next point: in flight during this one's pair loop
+        const F3 p = F3{cur.x, cur.y, cur.z};
+        const uint64_t info = s_info[__float_as_uint(cur.w) & (kBrickCells - 1)];
+        const uint32_t cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+        const uint64_t off = info >> kDepOffShift;
+        c_tested += cnt;
+        float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+        if (cnt) {
+            n0 = dep4[2 * off];
+            n1 = dep4[2 * off + 1];
         }
-#pragma unroll
-        for (int k = 0; k < kUpdPer; k++) {
-            const uint32_t i = tid + (uint32_t)kUpdThreads * (uint32_t)k;
-            if (i < n) rk[k] = atomicAdd(&s_hist[__float_as_uint(e[k].w) & (kBrickCells - 1)], 1u);
-        }
-        __syncthreads();
-        HFPF_ST(1);
-        // 2. runs and work items.  Items are grouped by the list length of their cell, so that the rows of one wave walk
-        //    lists of (almost always) the same length: the wave's trip count is then every row's own trip count.
-        uint32_t n_items;
-        {
-            const uint32_t h = s_hist[tid];
-            const uint32_t it = my_staged ? (h + kUpdRow - 1) / kUpdRow : 0u;  // cells without dependants need no work
-            if (tid <= (uint32_t)kUpdMaxList) s_cls[tid] = 0;
-            uint32_t total;
-            const uint32_t p0 = upd_block_scan(h, s_wsum[0], total);  // (barrier inside: s_cls is zero behind it)
-            s_hist[tid] = p0;
-            const uint32_t ib = it ? atomicAdd(&s_cls[my_cnt], it) : 0u;  // position inside the class (any order: the sums are integers)
-            __syncthreads();
-            if (tid < 64) {  // exclusive scan of the kUpdMaxList + 1 class sizes by one wave
-                const uint32_t c0 = s_cls[tid], c1 = tid == 0 ? s_cls[64] : 0u;  // class 64 rides on lane 0's second slot
-                uint32_t incl = c0;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t u = __shfl_up(incl, o);
-                    if (lane >= (uint32_t)o) incl += u;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const float4 e0 = n0, e1 = n1;
+            if (j + 1 < cnt) {  // next entry: in flight during this pair
+                n0 = dep4[2 * (off + j + 1)];
+                n1 = dep4[2 * (off + j + 1) + 1];
+            }
+            float sp, distf;
+            if (!line_member(g, p, F3{e0.y, e0.z, e0.w}, F3{e1.x, e1.y, e1.z}, e1.w, sp, distf)) continue;
+            c_member++;
+            const PairDelta q = pair_delta(g, sp, distf);
+            const uint32_t sid = __float_as_uint(e0.x);
+            uint32_t h = upd_hash(sid);
+            bool placed = false;
+            for (int probe = 0; probe < 16; probe++) {
+                const uint32_t old = atomicCAS(&keys[h], 0u, sid);
+                if (old == 0u || old == sid) {
+                    placed = true;
+                    break;
                 }
-                const uint32_t tot63 = __shfl(incl, 63);
-                s_cls[tid] = incl - c0;
-                if (tid == 0) {
-                    s_cls[64] = tot63;
-                    s_wsum[0][0] = tot63 + c1;  // n_items
+                h = (h + 1) & (kUpdSlots - 1);
+            }
+            unsigned long long* v = placed ? nullptr : &t.stats[(uint64_t)sid * kStatWords];  // table full: straight to HBM
+            if (placed) {
+                unsigned long long* sv = &vals[h * W];
+                atomicAdd(&sv[SW_COUNT], 1ull);
+                atomicAdd(&sv[SW_S], (unsigned long long)(long long)q.s);
+                atomicAdd(&sv[SW_SS], (unsigned long long)(long long)q.ss);
+                atomicAdd(&sv[SW_D], (unsigned long long)(long long)q.d);
+                atomicAdd(&sv[SW_DD], (unsigned long long)(long long)q.dd);
+                if constexpr (COLOR) {
+                    atomicAdd(&sv[SW_R], (unsigned long long)((rgb >> 16) & 255u));
+                    atomicAdd(&sv[SW_G], (unsigned long long)((rgb >> 8) & 255u));
+                    atomicAdd(&sv[SW_B], (unsigned long long)(rgb & 255u));
+                }
+            } else {
+                atomicAdd(&v[SW_COUNT], 1ull);
+                atomicAdd(&v[SW_S], (unsigned long long)(long long)q.s);
+                atomicAdd(&v[SW_SS], (unsigned long long)(long long)q.ss);
+                atomicAdd(&v[SW_D], (unsigned long long)(long long)q.d);
+                atomicAdd(&v[SW_DD], (unsigned long long)(long long)q.dd);
+                if constexpr (COLOR) {
+                    atomicAdd(&v[SW_R], (unsigned long long)((rgb >> 16) & 255u));
+                    atomicAdd(&v[SW_G], (unsigned long long)((rgb >> 8) & 255u));
+                    atomicAdd(&v[SW_B], (unsigned long long)(rgb & 255u));
                 }
             }
-            __syncthreads();
-            n_items = s_wsum[0][0];
-            const uint32_t i0 = s_cls[my_cnt <= (uint32_t)kUpdMaxList ? my_cnt : 0u] + ib;
-            for (uint32_t k = 0; k < it; k++) s_item[i0 + k] = (p0 + k * kUpdRow) | ((min((uint32_t)kUpdRow, h - k * kUpdRow) - 1u) << 12) | (tid << 16);
-        }
-        __syncthreads();
-        HFPF_ST(2);
-        // 3. scatter the points into cell order
-#pragma unroll
-        for (int k = 0; k < kUpdPer; k++) {
-            const uint32_t i = tid + (uint32_t)kUpdThreads * (uint32_t)k;
-            if (i < n) {
-                const uint32_t pos = s_hist[__float_as_uint(e[k].w) & (kBrickCells - 1)] + rk[k];
-                s_px[pos] = e[k].x;
-                s_py[pos] = e[k].y;
-                s_pz[pos] = e[k].z;
-                if (COLOR) s_rgb[pos] = crgb[k];
-            }
-        }
-        __syncthreads();
-        HFPF_ST(3);
-        // 4. rows x dependants, one group of ENT entries at a time (one group for all but the densest bricks)
-        for (uint32_t lo = 0; lo < n_ent; lo += (uint32_t)ENT) {  // block-uniform trip count
-            const uint32_t n_here = min(n_ent - lo, (uint32_t)ENT_ALLOC);
-            if (my_staged && my_eb >= lo && my_eb < lo + (uint32_t)ENT) {  // stage the lists that START in this group
-                const uint32_t d0 = 2u * (my_eb - lo);
-                for (uint32_t j = 0; j < my_cnt; j += 2) {  // two entries in flight per trip
-                    const uint64_t src = 2 * ((uint64_t)my_off + j);
-                    const bool two = j + 1 < my_cnt;
-                    const float4 a0 = dep4[src], a1 = dep4[src + 1];
-                    float4 b0 = a0, b1 = a1;
-                    if (two) {
-                        b0 = dep4[src + 2];
-                        b1 = dep4[src + 3];
-                    }
-                    s_ent[d0 + 2 * j] = a0;
-                    s_ent[d0 + 2 * j + 1] = a1;
-                    if (two) {
-                        s_ent[d0 + 2 * j + 2] = b0;
-                        s_ent[d0 + 2 * j + 3] = b1;
-                    }
-                }
-            }
-            for (uint32_t i = tid; i < n_here * W; i += (uint32_t)kUpdThreads) s_val[i] = 0;
-            __syncthreads();
-            HFPF_ST(4);
-            for (uint32_t ibase = 0; ibase < n_items; ibase += (uint32_t)kUpdRows) {  // block-uniform trip count
-                const uint32_t ii = ibase + row;
-                const bool rv = ii < n_items;
-                const uint32_t item = rv ? s_item[ii] : 0u;
-                const uint32_t cell = item >> 16;
-                const uint32_t ceb = s_eb[cell];
-                const bool here = rv && ceb >= lo && ceb < lo + (uint32_t)ENT;  // the cell's lists belong to this group
-                const bool pv = here && rl <= ((item >> 12) & 15u);
-                const uint32_t pos = (item & 0xFFFu) + rl;
-                F3 p = {0.f, 0.f, 0.f};
-                uint32_t rgb = 0;
-                if (pv) {
-                    p = F3{s_px[pos], s_py[pos], s_pz[pos]};
-                    if (COLOR) rgb = s_rgb[pos];
-                }
-                const uint32_t cnt = here ? (uint32_t)s_cnt[cell] : 0u;
-                const uint32_t ebase = ceb - lo;
-                uint32_t max_cnt = cnt;  // wave-uniform trip count: the longest list among the wave's rows
-#pragma unroll
-                for (int o = kUpdRow; o < 64; o <<= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, o));
-                if (pv) c_tested += cnt;
-                for (uint32_t j = 0; j < max_cnt; j++) {
-                    bool mem = false;
-                    PairDelta q = {0, 0, 0, 0};
-                    if (j < cnt) {
-                        const float4 e0 = s_ent[2 * (ebase + j)];  // the same address in every lane of the row
-                        const float4 e1 = s_ent[2 * (ebase + j) + 1];
-                        if (pv) {
-                            float sp, distf;
-                            mem = line_member(g, p, F3{e0.y, e0.z, e0.w}, F3{e1.x, e1.y, e1.z}, e1.w, sp, distf);
-                            if (mem) q = pair_delta(g, sp, distf);
-                        }
-                    }
-                    const unsigned long long mm = __ballot(mem);
-                    if (mm == 0) continue;  // wave-uniform
-                    const uint32_t row_members = (uint32_t)__popcll((mm >> (lane & ~(uint32_t)(kUpdRow - 1))) & ((1ull << kUpdRow) - 1ull));
-                    const int sum_s = row_sum(q.s), sum_ss = row_sum(q.ss);
-                    const int sum_d = row_sum(q.d), sum_dd = row_sum(q.dd);
-                    int sum_r = 0, sum_g = 0, sum_b = 0;
-                    if (COLOR) {
-                        sum_r = row_sum(mem ? (int)((rgb >> 16) & 255u) : 0);
-                        sum_g = row_sum(mem ? (int)((rgb >> 8) & 255u) : 0);
-                        sum_b = row_sum(mem ? (int)(rgb & 255u) : 0);
-                    }
-                    if (rl == 0 && row_members) {
-                        c_member += row_members;
-                        unsigned long long* sv = &s_val[(ebase + j) * W];
-                        atomicAdd(&sv[SW_COUNT], (unsigned long long)row_members);
-                        atomicAdd(&sv[SW_S], (unsigned long long)(long long)sum_s);
-                        atomicAdd(&sv[SW_SS], (unsigned long long)(long long)sum_ss);
-                        atomicAdd(&sv[SW_D], (unsigned long long)(long long)sum_d);
-                        atomicAdd(&sv[SW_DD], (unsigned long long)(long long)sum_dd);
-                        if constexpr (COLOR) {
-                            atomicAdd(&sv[SW_R], (unsigned long long)(long long)sum_r);
-                            atomicAdd(&sv[SW_G], (unsigned long long)(long long)sum_g);
-                            atomicAdd(&sv[SW_B], (unsigned long long)(long long)sum_b);
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            HFPF_ST(5);
-            {  // flush: 8 lanes per entry; entries nobody hit are skipped
-                const uint32_t w = tid & 7u;
-                for (uint32_t ei = tid >> 3; ei < n_here; ei += (uint32_t)kUpdThreads / 8) {
-                    if (s_val[ei * W + SW_COUNT] != 0ull && w < (uint32_t)W) {
-                        const uint32_t sid = __float_as_uint(s_ent[2 * ei].x);
-                        atomicAdd(&t.stats[(uint64_t)sid * kStatWords + w], s_val[ei * W + w]);
-                    }
-                }
-            }
-            __syncthreads();  // the next group (or round) restages s_ent / s_val, the next round rewrites the points
-            HFPF_ST(6);
         }
     }
-    if (any_long) {  // cells with more dependants than a group stages: one thread per point, straight from / to global memory
-        for (uint32_t i = tid; i < fill; i += (uint32_t)kUpdThreads) {
-            const float4 pe = t.bin_pt[first + i];
-            const uint32_t rgb = COLOR ? t.bin_rgb[first + i] : 0u;
-            const uint32_t cell = __float_as_uint(pe.w) & (kBrickCells - 1);
-            const uint32_t cnt = s_cnt[cell];
-            if (cnt <= (uint32_t)kUpdMaxList) continue;
-            const uint64_t off = s_off[cell];
-            c_tested += cnt;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const DepEntry e = t.dep[off + j];
-                float sp, distf;
-                if (!line_member(g, F3{pe.x, pe.y, pe.z}, F3{e.ax, e.ay, e.az}, F3{e.abx, e.aby, e.abz}, e.dd, sp, distf)) continue;
-                c_member++;
-                const PairDelta q = pair_delta(g, sp, distf);
-                unsigned long long* gv = &t.stats[(uint64_t)e.sid * kStatWords];
-                atomicAdd(&gv[SW_COUNT], 1ull);
-                atomicAdd(&gv[SW_S], (unsigned long long)(long long)q.s);
-                atomicAdd(&gv[SW_SS], (unsigned long long)(long long)q.ss);
-                atomicAdd(&gv[SW_D], (unsigned long long)(long long)q.d);
-                atomicAdd(&gv[SW_DD], (unsigned long long)(long long)q.dd);
-                if constexpr (COLOR) {
-                    atomicAdd(&gv[SW_R], (unsigned long long)((rgb >> 16) & 255u));
-                    atomicAdd(&gv[SW_G], (unsigned long long)((rgb >> 8) & 255u));
-                    atomicAdd(&gv[SW_B], (unsigned long long)(rgb & 255u));
-                }
-            }
+    __syncthreads();
+    {  // flush: 8 lanes per record, 32 records per pass
+        const uint32_t w = tid & 7u;
+        for (uint32_t sl = tid >> 3; sl < (uint32_t)kUpdSlots; sl += 32) {
+            const uint32_t key = keys[sl];
+            if (key != 0u && w < (uint32_t)W) atomicAdd(&t.stats[(uint64_t)key * kStatWords + w], vals[sl * W + w]);
         }
     }
 #pragma unroll
@@ -679,7 +459,7 @@ __global__ __launch_bounds__(512) void k_update(const GridParams g, const Tables
         c_tested += __shfl_down(c_tested, o);
         c_member += __shfl_down(c_member, o);
     }
-    if (lane == 0) {
+    if ((tid & 63u) == 0) {
         if (c_tested) atomicAdd(&blk_ctr[0], c_tested);
         if (c_member) atomicAdd(&blk_ctr[1], c_member);
     }
@@ -687,13 +467,6 @@ __global__ __launch_bounds__(512) void k_update(const GridParams g, const Tables
     // striped like k_replay's counter: words 2 and 3 of the 64 log_ctr lines, summed by the host
     if (tid < 2 && blk_ctr[tid])
         atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
-#ifdef HFPF_STAMP
-    HFPF_ST(7);
-    if (tid == 0) {
-        for (int k = 0; k < 8; k++) atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 5 + k], st_acc[k]);
-        atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 13], 1ull);
-    }
-#endif
 }
 
 // Plan the brick regions of the next launch from the demand of the previous one: cap = demand * scale * 1.25 + 64.
