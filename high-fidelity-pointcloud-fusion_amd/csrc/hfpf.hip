@@ -84,7 +84,11 @@ struct hfpf_handle {
     uint64_t frames_integrated = 0;
     uint64_t reg_done = 0;  // reg_occ entries already present in dep[]
     uint64_t gate_done = 0; // occ_list entries already examined by a gate pass
-    uint64_t n_pend = 0;    // cells examined before that still have no normal (pend_a)
+    // A capacity / HIP / collective error in the middle of a clean pass leaves the tables half updated: the handle then refuses
+    // further work (HFPF_ERR_STATE) until hfpf_clear, instead of silently losing candidates on a retry.
+    bool poisoned = false;
+    std::string poison_msg;
+    bool pend_valid = false; // pend_a holds C_PEND cells that a gate pass examined and left without a normal
     DevBuf pend_a, pend_b;
     uint64_t clean_passes = 0;
     uint32_t next_frame_id = 0;
@@ -138,6 +142,20 @@ int fail(hfpf_handle* h, int code, const char* fmt, ...)
     if (h) h->err = buf;
     else g_create_error = buf;
     return code;
+}
+
+int check_usable(hfpf_handle* h)
+{
+    if (!h->poisoned) return HFPF_OK;
+    return fail(h, HFPF_ERR_STATE, "handle failed earlier (%s); hfpf_clear resets it", h->poison_msg.c_str());
+}
+int poison_on_error(hfpf_handle* h, int rc)
+{
+    if ((rc == HFPF_ERR_CAPACITY || rc == HFPF_ERR_HIP || rc == HFPF_ERR_DIST) && !h->poisoned) {
+        h->poisoned = true;
+        h->poison_msg = h->err;
+    }
+    return rc;
 }
 
 #define HIPCHK(h, call)                                                                                        \
@@ -307,7 +325,9 @@ int reset_state(hfpf_handle* h)
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
     h->reg_done = 0;
     h->gate_done = 0;
-    h->n_pend = 0;
+    h->pend_valid = false;
+    h->poisoned = false;
+    h->poison_msg.clear();
     h->occ_exported = 0;
     h->next_frame_id = 0;
     return HFPF_OK;
@@ -659,21 +679,52 @@ int epoch_import_locked(hfpf_handle* h, const void* dev_records, uint64_t n)
     return HFPF_OK;
 }
 
-// RCCL exchange at the head of a clean pass: all-gather the counts, then the (padded) record lists.
+// Device records [0, n) of one rank's slice of a gathered exchange buffer -> this handle's tables.  The one place both
+// transports (RCCL all-gather below, hfpf_epoch_import for host-staged / virtual ranks) go through.
+int import_rank_slice_locked(hfpf_handle* h, const void* dev_buffer, uint64_t slice_stride_bytes, int src_rank, uint64_t n_records)
+{
+    if (n_records == 0) return HFPF_OK;
+    return epoch_import_locked(h, (const char*)dev_buffer + (size_t)src_rank * slice_stride_bytes, n_records);
+}
+
+// Every other rank's slice of an all-gathered buffer (world slices of slice_stride_bytes; slice r holds counts[r] records, the
+// rest of it is padding that is never read).
+int import_gathered_locked(hfpf_handle* h, const void* dev_buffer, uint64_t slice_stride_bytes, int world, int my_rank, const unsigned long long* counts)
+{
+    for (int r = 0; r < world; r++) {
+        if (r == my_rank) continue;
+        if (counts[r] * sizeof(EpochRec) > slice_stride_bytes) return fail(h, HFPF_ERR_BAD_ARG, "gathered slice %d: %llu records do not fit the stride", r, counts[r]);
+        if (int rc = import_rank_slice_locked(h, dev_buffer, slice_stride_bytes, r, counts[r])) return rc;
+    }
+    return HFPF_OK;
+}
+
+// RCCL exchange at the head of a clean pass: all-gather the counts, then the (padded) record lists.  A rank that failed
+// locally still takes part in the count gather and flags it there, so that every rank leaves the collective sequence at the
+// same point instead of blocking in a collective its peer never enters.
 int dist_exchange_locked(hfpf_handle* h)
 {
+    constexpr unsigned long long kFailBit = 1ull << 63;
     uint64_t n_mine = 0;
     int rc = epoch_export_locked(h, &n_mine, 0);
-    if (rc) return rc;
+    const int local_rc = rc;
+    if (local_rc) n_mine = 0;
     if ((rc = scratch(h, h->ex_counts, (size_t)(h->world + 1) * 8))) return rc;
     unsigned long long* d_counts = (unsigned long long*)h->ex_counts.p;
-    h->h_counts[h->world] = n_mine;
+    h->h_counts[h->world] = n_mine | (local_rc ? kFailBit : 0ull);
     HIPCHK(h, hipMemcpyAsync(d_counts + h->world, h->h_counts + h->world, 8, hipMemcpyHostToDevice, h->stream));
     NCCLCHK(h, g_rccl.AllGather(d_counts + h->world, d_counts, 1, ncclUint64_, (ncclComm_t_)h->comm, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_counts, d_counts, (size_t)h->world * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     uint64_t maxc = 0;
-    for (int r = 0; r < h->world; r++) maxc = std::max<uint64_t>(maxc, h->h_counts[r]);
+    int failed_rank = -1;
+    for (int r = 0; r < h->world; r++) {
+        if (h->h_counts[r] & kFailBit) failed_rank = r;
+        h->h_counts[r] &= ~kFailBit;
+        maxc = std::max<uint64_t>(maxc, h->h_counts[r]);
+    }
+    if (local_rc) return local_rc;  // h->err already says why
+    if (failed_rank >= 0) return fail(h, HFPF_ERR_DIST, "rank %d failed before the epoch exchange; this pass is abandoned on every rank", failed_rank);
     if (maxc == 0) return HFPF_OK;
     // the send buffer must hold maxc records (padding is never read by the importers)
     if (h->ex_send.bytes < maxc * sizeof(EpochRec)) {
@@ -687,23 +738,23 @@ int dist_exchange_locked(hfpf_handle* h)
     }
     if ((rc = scratch(h, h->ex_recv, (size_t)h->world * maxc * sizeof(EpochRec)))) return rc;
     NCCLCHK(h, g_rccl.AllGather(h->ex_send.p, h->ex_recv.p, maxc * sizeof(EpochRec), ncclChar_, (ncclComm_t_)h->comm, h->stream));
-    for (int r = 0; r < h->world; r++) {
-        if (r == h->rank || h->h_counts[r] == 0) continue;
-        if ((rc = epoch_import_locked(h, (const char*)h->ex_recv.p + (size_t)r * maxc * sizeof(EpochRec), h->h_counts[r]))) return rc;
-    }
-    return HFPF_OK;
+    return import_gathered_locked(h, h->ex_recv.p, maxc * sizeof(EpochRec), h->world, h->rank, h->h_counts);
 }
 
 // k_gate with four tiles per workgroup only when the input is large enough to fill the chip that way (one reservation per
 // list and workgroup; small inputs keep one tile so that the latency-heavy stencil probes spread over as many CUs as possible).
-void launch_gate(hfpf_handle* h, const uint32_t* cells, uint64_t n, uint32_t* pend_out)
+void launch_gate(hfpf_handle* h, const uint32_t* cells_a, uint64_t n_a, const uint32_t* cells_b, uint64_t n_b, uint32_t* pend_out)
 {
+    const uint64_t n = n_a + n_b;
     if (n >= (1ull << 20))
-        hipLaunchKernelGGL(k_gate<4>, dim3(blocks_for(n, 256 * 4)), dim3(256), 0, h->stream, h->g, h->t, cells, n, pend_out);
+        hipLaunchKernelGGL(k_gate<4>, dim3(blocks_for(n, 256 * 4)), dim3(256), 0, h->stream, h->g, h->t, cells_a, n_a, cells_b, n_b, pend_out);
     else
-        hipLaunchKernelGGL(k_gate<1>, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, h->t, cells, n, pend_out);
+        hipLaunchKernelGGL(k_gate<1>, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, h->t, cells_a, n_a, cells_b, n_b, pend_out);
 }
 
+// One clean pass.  Two host read-backs: at the start (what the integrate launches since the last pass produced) and after the
+// dependant-table update (how many cells to replay, overflow bits).  Everything between them is sized from upper bounds on the
+// host and reads its exact counts from the device counters.
 int clean_locked(hfpf_handle* h)
 {
     Tables& t = h->t;
@@ -714,6 +765,7 @@ int clean_locked(hfpf_handle* h)
     if ((rc = check_device_errors(h))) return rc;
     const uint64_t n_occ = std::min<uint64_t>(h->h_ctr[C_OCC], t.max_occ);
     const uint64_t n_normals = h->h_ctr[C_NORMALS];
+    const uint64_t n_pend = h->pend_valid ? h->h_ctr[C_PEND] : 0;  // cells the previous pass left without a normal (pend_a)
     h->occ_exported = n_occ;  // everything occupied so far (locally or imported) has been exchanged
     h->dirty = false;  // state_changed = false, grid.hpp:313
     h->clean_passes++;
@@ -738,35 +790,29 @@ int clean_locked(hfpf_handle* h)
 
     // candidates: the cells that failed the gate last time (pending list) + the cells occupied since (new tail of occ_list)
     const uint64_t n_new_occ = n_occ - std::min(n_occ, h->gate_done);
-    if ((rc = scratch(h, h->pend_b, std::max<uint64_t>(h->n_pend + n_new_occ, 1) * 4))) return rc;
+    const uint64_t n_in = n_pend + n_new_occ;  // upper bound of everything this pass can produce per candidate
+    if (n_in == 0) return HFPF_OK;
+    if ((rc = scratch(h, h->pend_b, n_in * 4))) return rc;
+    if ((rc = scratch(h, h->keys_a, n_in * 8))) return rc;
     hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull, (int)C_PEND, 0ull, (int)C_PRECHG, 0ull);
-    if (h->n_pend)
-        launch_gate(h, (const uint32_t*)h->pend_a.p, h->n_pend, (uint32_t*)h->pend_b.p);
-    if (n_new_occ)
-        launch_gate(h, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, (uint32_t*)h->pend_b.p);
+    HIPCHK(h, hipMemsetAsync(t.cand_key, 0xFF, n_in * 8, s));  // all-ones sentinels behind the real candidates: they sort to the end
+    launch_gate(h, (const uint32_t*)h->pend_a.p, n_pend, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, (uint32_t*)h->pend_b.p);
     HIPCHK(h, hipGetLastError());
     h->gate_done = n_occ;
-    if ((rc = read_counters(h))) return rc;
-    const uint64_t n_cand = h->h_ctr[C_CAND];
     std::swap(h->pend_a, h->pend_b);  // cells that got a normal in this pass are dropped by the next gate's kNormal test
-    h->n_pend = h->h_ctr[C_PEND];
-    if (n_cand == 0) return HFPF_OK;
-    if (n_normals + n_cand > t.max_normals)
-        return fail(h, HFPF_ERR_CAPACITY, "normal records: %llu + %llu > max_normals %llu", (unsigned long long)n_normals,
-                    (unsigned long long)n_cand, (unsigned long long)t.max_normals);
+    h->pend_valid = true;             // C_PEND now counts pend_a; the host reads it at the start of the next pass
 
-    // canonical order: ascending (x,y,z) key
-    if ((rc = scratch(h, h->keys_a, n_cand * 8))) return rc;
-    if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_cand))) return rc;
-    hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_cand, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, n_cand, n_normals);
+    // canonical order: ascending (x,y,z) key; record id = n_normals + rank + 1
+    if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_in))) return rc;
+    hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_in, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, kCountOnDevice, n_normals);
     const uint64_t reg_tile = 256ull * kRegTiles;  // step-major, whole workgroups (kRegTiles tiles each) per step
-    const uint64_t reg_blocks = ((n_cand + reg_tile - 1) / reg_tile) * (2ull * (uint64_t)h->g.K + 1ull);
-    hipLaunchKernelGGL(k_register, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, n_cand, n_normals);
-    hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_NORMALS, (unsigned long long)(n_normals + n_cand), (int)C_TOUCHED, 0ull, -1, 0ull);
+    const uint64_t reg_blocks = ((n_in + reg_tile - 1) / reg_tile) * (2ull * (uint64_t)h->g.K + 1ull);
+    hipLaunchKernelGGL(k_register, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals);
+    hipLaunchKernelGGL(k_commit_normals, dim3(1), dim3(1), 0, s, t, n_normals);
     HIPCHK(h, hipGetLastError());
-    // No readback here: the registration counts of this pass are bounded by (2K+1) * n_cand, the kernels below read the exact
-    // counts from the device counters (kCountOnDevice), and the host picks the values up at the readback after them.
-    const uint64_t reg_ub = (2ull * (uint64_t)h->g.K + 1ull) * n_cand;
+    // The registration counts of this pass are bounded by (2K+1) * n_in; the kernels below read the exact counts from the
+    // device counters (kCountOnDevice), and the host picks the values up at the read-back after them.
+    const uint64_t reg_ub = (2ull * (uint64_t)h->g.K + 1ull) * n_in;
     uint64_t n_reg = 0, n_pre = 0, inc_touched = 0;
     // incremental update; a conservative space estimate decides whether to compact instead (C_DEP as of the last readback:
     // nothing has changed it since)
@@ -817,14 +863,18 @@ int clean_locked(hfpf_handle* h)
     }
     // buffer replay of the cells that gained registrants in this pass (touched_list is still intact)
     if (inc_touched) {
-        // a 256-point tile appends consecutive log entries for neighbouring cells, so walking the cells in slot
-        // (brick-major) order lets adjacent lanes share cache lines of the log
-        if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
-        if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched))) return rc;
+        // a 256-point tile appends consecutive log entries for neighbouring cells, so walking the cells in slot (brick-major)
+        // order lets adjacent lanes share cache lines of the log; a short list is not worth the sort's nine launches
+        const uint32_t* cells = t.touched_list;
+        if (inc_touched >= (1ull << 18)) {
+            if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
+            if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched))) return rc;
+            cells = (const uint32_t*)h->vals_a.p;
+        }
         if (t.color)
-            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, inc_touched, n_normals);
         else
-            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)h->vals_a.p, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, inc_touched, n_normals);
         HIPCHK(h, hipGetLastError());
     }
     h->reg_done = n_reg;
@@ -971,6 +1021,7 @@ int hfpf_integrate_device(hfpf_handle* h, const void* dev_base, uint32_t n_frame
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rc = check_usable(h)) return rc;
     return integrate_device_locked(h, dev_base, n_frames, frame_stride, n_points, point_step, off_x, off_y, off_z, off_rgb, poses, frame_ids);
 }
 
@@ -981,6 +1032,7 @@ int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (!base || !pose) return fail(h, HFPF_ERR_BAD_ARG, "integrate: null buffer or pose");
+    if (int rc0 = check_usable(h)) return rc0;
     if (n_points == 0) {
         h->next_frame_id++;
         h->frames_integrated++;
@@ -1027,7 +1079,8 @@ int hfpf_clean(hfpf_handle* h)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (!h->timing) return clean_locked(h);
+    if (int rc0 = check_usable(h)) return rc0;
+    if (!h->timing) return poison_on_error(h, clean_locked(h));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto get = [&](hipEvent_t& e) -> hipError_t {
         if (!h->ev_free.empty()) {
@@ -1040,7 +1093,7 @@ int hfpf_clean(hfpf_handle* h)
     HIPCHK(h, get(e0));
     HIPCHK(h, get(e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));  // after every queued integrate: measures the clean pass alone
-    const int rc = clean_locked(h);
+    const int rc = poison_on_error(h, clean_locked(h));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     h->ev_pending_clean.emplace_back(e0, e1);
     return rc;
@@ -1089,9 +1142,10 @@ int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
     *rows = nullptr;
     *n_rows = 0;
     Tables& t = h->t;
-    int rc = read_counters(h);
+    int rc = check_usable(h);
     if (rc) return rc;
-    if ((rc = check_device_errors(h))) return rc;
+    if ((rc = read_counters(h))) return rc;
+    if ((rc = check_device_errors(h))) return poison_on_error(h, rc);
     const unsigned long long* stats = t.stats;
     if (h->dist_on) {
         // Sum the ranks' private partial records (exact integer adds) into scratch; the partials stay intact.
@@ -1155,6 +1209,30 @@ int hfpf_epoch_import(hfpf_handle* h, const void* dev_records, uint64_t n_record
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));  // the caller may reuse / free the record buffer
     h->dirty = true;
+    return HFPF_OK;
+}
+
+int hfpf_epoch_import_gathered(hfpf_handle* h, const void* dev_buffer, uint64_t slice_stride_bytes, int32_t world, int32_t my_rank, const uint64_t* counts)
+{
+    if (!h || !dev_buffer || !counts || world < 1 || my_rank < 0 || my_rank >= world) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rc0 = check_usable(h)) return rc0;
+    std::vector<unsigned long long> c(counts, counts + world);
+    int rc = import_gathered_locked(h, dev_buffer, slice_stride_bytes, world, my_rank, c.data());
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the caller may reuse / free the buffer
+    h->dirty = true;
+    return HFPF_OK;
+}
+
+int hfpf_device_copy(hfpf_handle* h, void* dev_dst, const void* dev_src, uint64_t bytes)
+{
+    if (!h || (!dev_dst && bytes) || (!dev_src && bytes)) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (bytes) HIPCHK(h, hipMemcpyAsync(dev_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return HFPF_OK;
 }
 
@@ -1372,7 +1450,7 @@ int hfpf_sync(hfpf_handle* h)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = read_counters(h);
     if (rc) return rc;
-    return check_device_errors(h);
+    return poison_on_error(h, check_device_errors(h));
 }
 
 int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)

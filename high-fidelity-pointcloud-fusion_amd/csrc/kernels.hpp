@@ -543,11 +543,13 @@ __device__ inline void neighbourhood(const GridParams& g, const Tables& t, int32
 // K3: every occupied cell without a normal is a candidate (the reference's unprocessed_data_ set is
 // a superset whose extra members fail the same gate, grid.hpp:315,352).
 template <int TILES>
-__global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint64_t n_cells,
-                                              uint32_t* __restrict__ pend_out)
+__global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t, const uint32_t* __restrict__ cells_a, const uint64_t n_a,
+                                              const uint32_t* __restrict__ cells_b, const uint64_t n_b, uint32_t* __restrict__ pend_out)
 {
+    // Input = the cells that failed the gate last time (cells_a) followed by the cells occupied since (cells_b), one launch.
     // TILES tiles per workgroup, one reservation per output list (hot list counters: see k_register).  The host uses
     // TILES = 4 only for large inputs: the stencil probe is latency-heavy and a small grid needs every workgroup it can get.
+    const uint64_t n_cells = n_a + n_b;
     uint64_t key_[TILES];
     uint32_t slot_[TILES];
     uint32_t n_pass[TILES], n_pend[TILES];
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t
         slot_[tt] = 0;
         n_pass[tt] = n_pend[tt] = 0;
         if (j < n_cells) {
-            const uint32_t slot = cells[j];
+            const uint32_t slot = j < n_a ? cells_a[j] : cells_b[j - n_a];
             slot_[tt] = slot;
             if (!(t.info[slot] & kNormal)) {
                 int32_t x, y, z;
@@ -583,10 +585,29 @@ __global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t
     }
 }
 
+// Candidates of the running pass as the kernels after the gate see them: the device counter, clamped to the room left in the
+// normal records (the host learns the exact number at its next read-back; E_NORMALS reports the clamp).
+__device__ __forceinline__ uint64_t cand_count(const Tables& t, uint64_t base)
+{
+    const uint64_t n = t.ctr[C_CAND];
+    const uint64_t room = t.max_normals > base ? t.max_normals - base : 0;
+    return n < room ? n : room;
+}
+// After k_normal / k_register: publish the new record count, reset the touched-cell counter of the dependant-table update.
+__global__ void k_commit_normals(const Tables t, const uint64_t base)
+{
+    if (t.ctr[C_CAND] > cand_count(t, base)) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_NORMALS);
+    t.ctr[C_NORMALS] = base + cand_count(t, base);
+    t.ctr[C_TOUCHED] = 0;
+}
+
 // K4: one thread per candidate, in ascending key order; record id = base + rank + 1.
 __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables t, const uint64_t* __restrict__ sorted_keys,
-                                                const uint64_t n_cand, const uint64_t base)
+                                                const uint64_t n_cand_arg, const uint64_t base)
 {
+    // n_cand_arg = kCountOnDevice: the grid covers an upper bound (the gate's input size), the sorted keys behind the real
+    // candidates are all-ones sentinels
+    const uint64_t n_cand = n_cand_arg == kCountOnDevice ? cand_count(t, base) : n_cand_arg;
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_cand) return;
     const uint64_t key = sorted_keys[r];
@@ -651,8 +672,10 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
 // K5: one thread per (new normal, line step).  Occupancy is frozen during a clean pass, so the steps are
 // independent; "last registrant wins" on unoccupied cells (grid.hpp:443-449) is an atomicMax over
 // record ids, which ascend with the canonical key order inside a pass and across passes.
-__global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand, const uint64_t base)
+__global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand_arg, const uint64_t base)
 {
+    const uint64_t n_cand = n_cand_arg == kCountOnDevice ? cand_count(t, base) : n_cand_arg;  // the same in every thread
+    if (n_cand == 0) return;
     // Step-major mapping: a wave holds 64 key-adjacent voxels at the SAME step, so its targets sit in the same few bricks.
     // A workgroup takes kRegTiles consecutive 256-voxel tiles of one step and reserves its list entries once per list: the
     // three list counters share a line, and same-line device atomics retire one per ~12 ns whoever issues them.

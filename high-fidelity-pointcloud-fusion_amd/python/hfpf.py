@@ -81,7 +81,7 @@ EXPORTS = [
     "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
     "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
     "hfpf_dist_unique_id", "hfpf_dist_init", "hfpf_dist_info", "hfpf_dist_disable", "hfpf_epoch_export", "hfpf_epoch_import", "hfpf_stats_export",
-    "hfpf_extract_with_stats", "hfpf_device_download",
+    "hfpf_extract_with_stats", "hfpf_device_download", "hfpf_device_copy", "hfpf_epoch_import_gathered",
 ]
 
 EPOCH_REC_DTYPE = np.dtype([("key", "<u8"), ("first_frame", "<u4"), ("vx", "<f4"), ("vy", "<f4"), ("vz", "<f4"), ("pad", "<u4", (2,))])
@@ -147,6 +147,8 @@ def lib():
     L.hfpf_stats_export.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
     L.hfpf_extract_with_stats.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(u64)]
     L.hfpf_device_download.argtypes = [vp, vp, vp, u64]
+    L.hfpf_device_copy.argtypes = [vp, vp, vp, u64]
+    L.hfpf_epoch_import_gathered.argtypes = [vp, vp, u64, i32, i32, vp]
     _lib = L
     return L
 
@@ -315,6 +317,14 @@ class OccupancyGrid:
 
     def epoch_import(self, dev_ptr, n_records):
         self._chk(lib().hfpf_epoch_import(self._h, C.c_void_p(dev_ptr), n_records))
+
+    def epoch_import_gathered(self, dev_buffer, slice_stride_bytes, world, my_rank, counts):
+        """Import every other rank's slice of a padded all-gather buffer (the layout ncclAllGather leaves behind)."""
+        c = np.ascontiguousarray(counts, dtype=np.uint64)
+        self._chk(lib().hfpf_epoch_import_gathered(self._h, C.c_void_p(dev_buffer), slice_stride_bytes, world, my_rank, _p(c)))
+
+    def device_copy(self, dev_dst, dev_src, nbytes):
+        self._chk(lib().hfpf_device_copy(self._h, C.c_void_p(dev_dst), C.c_void_p(dev_src), nbytes))
 
     def stats_export(self):
         """-> (dev ptr, n_words, colour dev ptr or 0, n_colour_words) of this handle's partial int64 sums."""

@@ -131,15 +131,31 @@ class HostStagedTransport:
 class LocalVirtualRanks:
     """Several handles on one GPU in one process standing in for ranks (tests): same protocol, device-to-device."""
 
-    def __init__(self, grids):
+    def __init__(self, grids, gathered=False):
+        """gathered=True moves the records the way the RCCL path does: one padded buffer of world slices (what
+        ncclAllGather leaves on every rank), imported with hfpf_epoch_import_gathered."""
         self.grids = grids
+        self.gathered = gathered
 
     def clean_all(self):
         exports = [g.epoch_export() for g in self.grids]
-        for i, g in enumerate(self.grids):
-            for j, (ptr, n) in enumerate(exports):
-                if i != j and n:
-                    g.epoch_import(ptr, n)
+        if self.gathered:
+            world = len(self.grids)
+            counts = np.array([n for _, n in exports], dtype=np.uint64)
+            stride = max(int(counts.max()), 1) * EPOCH_REC_BYTES
+            g0 = self.grids[0]
+            buf = g0.device_alloc(world * stride)
+            for r, (ptr, n) in enumerate(exports):
+                if n:
+                    g0.device_copy(buf + r * stride, ptr, n * EPOCH_REC_BYTES)
+            for i, g in enumerate(self.grids):
+                g.epoch_import_gathered(buf, stride, world, i, counts)
+            g0.device_free(buf)
+        else:
+            for i, g in enumerate(self.grids):
+                for j, (ptr, n) in enumerate(exports):
+                    if i != j and n:
+                        g.epoch_import(ptr, n)
         for g in self.grids:
             g.clean()
 

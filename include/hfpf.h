@@ -208,9 +208,15 @@ int hfpf_epoch_export(hfpf_handle* h, const void** dev_records, uint64_t* n_reco
 int hfpf_epoch_import(hfpf_handle* h, const void* dev_records, uint64_t n_records);
 /* Since ABI 3 the optional colour sums are words 5-7 of the same 8-word records: *dev_cwords is NULL, *n_cwords 0, and
  * hfpf_extract_with_stats ignores dev_cwords (both parameters are kept so that ABI-2 callers still link). */
+/* The receive side of a padded all-gather, as the RCCL path runs it: `world` slices of slice_stride_bytes each, slice r holding
+ * counts[r] 32-byte records (padding behind them is never read); every slice but my_rank's is imported.  Unequal and zero
+ * counts are the normal case. */
+int hfpf_epoch_import_gathered(hfpf_handle* h, const void* dev_buffer, uint64_t slice_stride_bytes, int32_t world, int32_t my_rank,
+                               const uint64_t* counts);
 int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words, const void** dev_cwords, uint64_t* n_cwords);
 int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* dev_cwords, hfpf_row** rows, uint64_t* n_rows);
 int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, uint64_t bytes);
+int hfpf_device_copy(hfpf_handle* h, void* dev_dst, const void* dev_src, uint64_t bytes); /* device to device, synchronous */
 
 /* ---- measurement: HIP-event timing of the engine's own kernels on the engine's stream ----
  * kernel ids: 0 = k_integrate launches, 1 = whole clean passes (first to last kernel of hfpf_clean, host read-backs

@@ -10,16 +10,17 @@ pytestmark = pytest.mark.gpu
 SMALL = dict(max_bricks=60000, max_log_points=4 << 20, max_normals=1 << 20, max_frames=4096)
 
 
-def _run_virtual(hfpf_mod, sc, world, fuse_color=False):
+def _run_virtual(hfpf_mod, sc, world, fuse_color=False, deal=None, gathered=False):
     import hfpf_dist
     grids = [hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, fuse_color=fuse_color, **SMALL) for _ in range(world)]
-    vr = hfpf_dist.LocalVirtualRanks(grids)
+    vr = hfpf_dist.LocalVirtualRanks(grids, gathered=gathered)
+    deal = deal or (lambda f: f % world)
     fb = sc.W * sc.H * 16
     try:
         for ev in sc.schedule():
             if ev[0] == "integrate":
                 f = ev[1]
-                g = grids[f % world]
+                g = grids[deal(f)]
                 dev = g.device_alloc(fb)
                 g.device_upload(dev, sc.frame(f))
                 g.integrate_device(dev, 1, fb, sc.W * sc.H, sc.poses[f].reshape(1, 12), frame_ids=np.array([f], np.uint32))
@@ -61,6 +62,41 @@ def test_virtual_ranks_viewpoint_latch_is_global_min(hfpf_mod, synth_mod):
         single = scenes.run(one, sc, "integrate")
     rows, _, _ = _run_virtual(hfpf_mod, sc, 2)
     assert rows.tobytes() == single.tobytes()
+
+
+def test_gathered_import_unequal_and_zero_counts(hfpf_mod, synth_mod):
+    """The receive side of the RCCL exchange (one padded all-gather buffer, per-rank counts and slice offsets:
+    hfpf_epoch_import_gathered, the function dist_exchange_locked calls) with unequal per-rank counts, one of them zero:
+    rank 2 gets no frame before the first clean, rank 0 two frames, rank 1 one."""
+    sc = scenes.Scene(7, 160, 120, 0.001, fx=615.0, clean_every=3)
+    owner = {0: 0, 1: 1, 2: 0, 3: 2, 4: 2, 5: 1, 6: 2}
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as one:
+        single = scenes.run(one, sc, "integrate")
+    rows, _, ctrs = _run_virtual(hfpf_mod, sc, 3, deal=lambda f: owner[f], gathered=True)
+    assert rows.tobytes() == single.tobytes()
+    assert [c["frames_integrated"] for c in ctrs] == [2, 2, 3]
+    rows2, _, _ = _run_virtual(hfpf_mod, sc, 3, deal=lambda f: owner[f], gathered=False)  # the record-list transport agrees
+    assert rows2.tobytes() == single.tobytes()
+
+
+def test_failed_clean_poisons_the_handle_until_clear(hfpf_mod, synth_mod):
+    """A capacity error in the middle of a clean pass leaves the tables half updated: the handle refuses further work
+    (HFPF_ERR_STATE) until hfpf_clear instead of silently losing candidates on a retry."""
+    sc = scenes.Scene(2, 160, 120, 0.001, fx=615.0)
+    caps = dict(SMALL, max_normals=256)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **caps) as g:
+        g.integrate(sc.frame(0), sc.poses[0])
+        with pytest.raises(hfpf_mod.HfpfError) as e:
+            g.clean()
+        assert e.value.code == -3
+        for call in (lambda: g.integrate(sc.frame(1), sc.poses[1]), g.clean, g.extract):
+            with pytest.raises(hfpf_mod.HfpfError) as e2:
+                call()
+            assert e2.value.code == -5 and "hfpf_clear" in str(e2.value)
+        g.clear()
+        assert len(g.extract()) == 0
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as g:  # and a roomy handle is unaffected
+        assert len(scenes.run(g, sc, "integrate")) > 1000
 
 
 def test_virtual_ranks_with_colour(oracle_mod, hfpf_mod, synth_mod):
