@@ -468,6 +468,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     if (std::max(std::max(off_x, off_y), std::max(off_z, off_rgb)) + 4 > point_step)
         return fail(h, HFPF_ERR_BAD_ARG, "integrate: field offset beyond point_step");
     if (n_frames > 65535) return fail(h, HFPF_ERR_BAD_ARG, "integrate: at most 65535 frames per call");
+    if ((uint64_t)blocks_for(n_points, 256) * n_frames >= 0xFFFFFFFFull) return fail(h, HFPF_ERR_BAD_ARG, "integrate: batch too large (split the call)");
     StageSlot* s = nullptr;
     int rc = acquire_stage(h, n_frames, &s);
     if (rc) return rc;

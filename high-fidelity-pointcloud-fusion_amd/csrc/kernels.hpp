@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
     __syncthreads();
 
     const uint32_t tiles_per_frame = (n_pts + 255u) >> 8;
-    const uint64_t n_tiles = (uint64_t)tiles_per_frame * n_frames;
+    const uint64_t n_tiles = (uint64_t)tiles_per_frame * n_frames;  // < 2^32 (host-checked)
     // log_rot changes from launch to launch, so that launches with fewer than kLogRegions workgroups (small frames through
     // hfpf_integrate, one frame per call) still fill every append region of the log
     const uint32_t region = (blockIdx.x + log_rot) & (kLogRegions - 1);
@@ -141,16 +141,37 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
     const uint64_t log_base = (uint64_t)region * t.log_region_cap;
     uint32_t c_present = 0, c_z = 0, c_in = 0, c_buf = 0, c_tested = 0, c_member = 0;
 
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t f = (uint32_t)(tile / tiles_per_frame);
-        // row_w != 0 (host-checked: organised frame, width and rows multiples of 16): the tile is a 16x16-pixel patch, whose
-        // points fall into ~2x2 bricks and half as many table lines as a 256-pixel run of one image row;
-        uint32_t i = (uint32_t)(tile % tiles_per_frame) * 256u + threadIdx.x;
+    // Where tile `tl` sits: frame and point index of this thread.  row_w != 0 (host-checked: organised frame, width and rows
+    // multiples of 16): the tile is a 16x16-pixel patch, whose points fall into ~2x2 bricks and half as many table lines as a
+    // 256-pixel run of one image row; each wave takes one 8x8 quadrant of the patch (8 pixels x 16 B = one 128-byte line per
+    // image row).  32-bit arithmetic: the host keeps n_tiles below 2^32.
+    auto locate = [&](uint32_t tl, uint32_t& f_out, uint32_t& i_out) {
+        f_out = tl / tiles_per_frame;
+        const uint32_t tile_in_frame = tl - f_out * tiles_per_frame;
+        i_out = tile_in_frame * 256u + threadIdx.x;
         if (row_w) {
-            const uint32_t tile_in_frame = (uint32_t)(tile % tiles_per_frame), tiles_x = row_w >> 4;
-            // each wave takes one 8x8 quadrant of the patch (8 pixels x 16 B = one 128-byte line per image row)
+            const uint32_t tiles_x = row_w >> 4, ty = tile_in_frame / tiles_x, tx = tile_in_frame - ty * tiles_x;
             const uint32_t px = ((threadIdx.x >> 6) & 1u) * 8u + (threadIdx.x & 7u), py = (threadIdx.x >> 7) * 8u + ((threadIdx.x >> 3) & 7u);
-            i = ((tile_in_frame / tiles_x) * 16u + py) * row_w + (tile_in_frame % tiles_x) * 16u + px;
+            i_out = (ty * 16u + py) * row_w + tx * 16u + px;
+        }
+    };
+    // The frame read of the NEXT tile is issued before this tile's table lookups (packed records only): the stream from HBM
+    // is the longest latency of a tile and nothing in the tile depends on it but its own first instruction.
+    uint32_t pre_f = 0, pre_i = 0;
+    vf4 pre = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t n_tiles32 = (uint32_t)n_tiles;
+    if (blockIdx.x < n_tiles32) {
+        locate(blockIdx.x, pre_f, pre_i);
+        if (PACKED16 && pre_i < n_pts)
+            pre = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(frames + (uint64_t)pre_f * frame_stride) + pre_i);  // read once
+    }
+    for (uint32_t tile = blockIdx.x; tile < n_tiles32; tile += gridDim.x) {
+        const uint32_t f = pre_f, i = pre_i;
+        const vf4 nv = pre;
+        if (tile + gridDim.x < n_tiles32) {
+            locate(tile + gridDim.x, pre_f, pre_i);
+            if (PACKED16 && pre_i < n_pts)
+                pre = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(frames + (uint64_t)pre_f * frame_stride) + pre_i);
         }
         double T[12];
 #pragma unroll
@@ -167,12 +188,10 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         uint32_t rgb = 0;
         if (act) {
             if (PACKED16) {
-                const vf4 nv = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(base) + i);  // read once
-                const float4 v = make_float4(nv.x, nv.y, nv.z, nv.w);
-                x = v.x;
-                y = v.y;
-                z = v.z;
-                rgb = __float_as_uint(v.w);
+                x = nv.x;
+                y = nv.y;
+                z = nv.z;
+                rgb = __float_as_uint(nv.w);
             } else {
                 const uint8_t* rec = base + (uint64_t)i * lay.point_step;
                 x = *reinterpret_cast<const float*>(rec + lay.off_x);
@@ -291,6 +310,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
                 }
             }
         }
+        if (__ballot(direct) == 0) continue;  // wave-uniform; the common case of the binned form
         uint32_t cnt = 0;
         uint64_t off = 0;
         if (direct) {

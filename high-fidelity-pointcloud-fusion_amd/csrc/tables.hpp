@@ -159,9 +159,13 @@ HFPF_HD uint32_t compact3(uint32_t v)  // inverse of spread3 on bits 0,3,6
 {
     return (v & 1u) | ((v >> 2) & 2u) | ((v >> 4) & 4u);
 }
+HFPF_HD uint32_t spread3_lut(uint32_t v)  // the same for v in 0..7: byte v of a packed table (two instructions)
+{
+    return (uint32_t)(0x4948414009080100ull >> (v * 8u)) & 0xFFu;
+}
 HFPF_HD uint32_t local_index(int32_t x, int32_t y, int32_t z)
 {
-    return (spread3((uint32_t)x & 7u) << 2) | (spread3((uint32_t)y & 7u) << 1) | spread3((uint32_t)z & 7u);
+    return (spread3_lut((uint32_t)x & 7u) << 2) | (spread3_lut((uint32_t)y & 7u) << 1) | spread3_lut((uint32_t)z & 7u);
 }
 
 // Cell coordinates of a slot (inverse of the two functions above).
