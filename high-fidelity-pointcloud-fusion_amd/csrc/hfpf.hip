@@ -1101,8 +1101,14 @@ int hfpf_clean(hfpf_handle* h)
 }
 
 // Shared tail of extract: `stats` are the (possibly merged) sums to finalise.
-static int extract_locked(hfpf_handle* h, const unsigned long long* stats, hfpf_row** rows, uint64_t* n_rows)
+static int extract_locked(hfpf_handle* h, const unsigned long long* stats, const hfpf_extract_opts* o, hfpf_row** rows, uint64_t* n_rows)
 {
+    ExtractOpts opt{0.0, -1, 0};
+    if (o) {
+        opt.min_count = o->min_count;
+        opt.classify_threshold = o->classify_threshold;
+        opt.paint_white = o->paint_white ? 1 : 0;
+    }
     Tables& t = h->t;
     int rc;
     const uint64_t n = h->h_ctr[C_NORMALS];
@@ -1112,14 +1118,14 @@ static int extract_locked(hfpf_handle* h, const unsigned long long* stats, hfpf_
     if ((rc = scratch(h, h->vals_a, n * 4))) return rc;
     if ((rc = scratch(h, h->vals_b, n * 4))) return rc;
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, h->stream, t.ctr, (int)C_ROWS, 0ull);
-    hipLaunchKernelGGL(k_extract_keys, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, t, n, (uint64_t*)h->keys_a.p, (uint32_t*)h->vals_a.p);
+    hipLaunchKernelGGL(k_extract_keys, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, t, stats, n, opt, (uint64_t*)h->keys_a.p, (uint32_t*)h->vals_a.p);
     HIPCHK(h, hipGetLastError());
     if ((rc = sort_pairs_u64(h, (uint64_t*)h->keys_a.p, (uint64_t*)h->keys_b.p, (uint32_t*)h->vals_a.p, (uint32_t*)h->vals_b.p, n))) return rc;
     if ((rc = read_counters(h))) return rc;
     const uint64_t nr = h->h_ctr[C_ROWS];
     if (nr == 0) return HFPF_OK;
     if ((rc = scratch(h, h->rows_dev, nr * sizeof(Row)))) return rc;
-    hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, stats, nr, (const uint64_t*)h->keys_b.p,
+    hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, stats, nr, opt, (const uint64_t*)h->keys_b.p,
                        (const uint32_t*)h->vals_b.p, (Row*)h->rows_dev.p);
     HIPCHK(h, hipGetLastError());
     hfpf_row* host = (hfpf_row*)malloc(nr * sizeof(hfpf_row));
@@ -1135,9 +1141,12 @@ static int extract_locked(hfpf_handle* h, const unsigned long long* stats, hfpf_
     return HFPF_OK;
 }
 
-int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
+int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows) { return hfpf_extract_filtered(h, nullptr, rows, n_rows); }
+
+int hfpf_extract_filtered(hfpf_handle* h, const hfpf_extract_opts* opts, hfpf_row** rows, uint64_t* n_rows)
 {
     if (!h || !rows || !n_rows) return HFPF_ERR_BAD_ARG;
+    if (opts && opts->struct_size != sizeof(hfpf_extract_opts)) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     *rows = nullptr;
@@ -1156,7 +1165,7 @@ int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows)
         NCCLCHK(h, g_rccl.AllReduce(t.stats, h->stats_total.p, words, ncclUint64_, ncclSum_, (ncclComm_t_)h->comm, h->stream));
         stats = (const unsigned long long*)h->stats_total.p;
     }
-    return extract_locked(h, stats, rows, n_rows);
+    return extract_locked(h, stats, opts, rows, n_rows);
 }
 
 int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* dev_cwords, hfpf_row** rows, uint64_t* n_rows)
@@ -1170,7 +1179,7 @@ int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* d
     if (rc) return rc;
     if ((rc = check_device_errors(h))) return rc;
     (void)dev_cwords;  // colour sums travel in words 5-7 of the statistics records since ABI 3
-    return extract_locked(h, (const unsigned long long*)dev_words, rows, n_rows);
+    return extract_locked(h, (const unsigned long long*)dev_words, nullptr, rows, n_rows);
 }
 
 int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words, const void** dev_cwords, uint64_t* n_cwords)

@@ -1089,8 +1089,18 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
 // ---- K6 extract -----------------------------------------------------------------------------------
 // Keys of the records that downloadData would emit: x<xdim && y<ydim && z<zdim (grid.hpp:463-465);
 // others get the all-ones key and sort to the end.
-__global__ __launch_bounds__(256) void k_extract_keys(const GridParams g, const Tables t, const uint64_t n_normals,
-                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+// The reference's alternate extractors (grid.hpp:491-601) are this one scan with two knobs (= hfpf_extract_opts):
+//   min_count           downloadHQ(cloud, threshold): `if (data->count < threshold) continue;` -- applied HERE, so filtered
+//                       rows never reach the sort's front, the row kernel or the host
+//   classify / paint    downloadClassified / download(XYZRGB): colour coding in k_extract_rows
+struct ExtractOpts {
+    double min_count;
+    int32_t classify_threshold;  // < 0: off; else rows with count > threshold are painted red, the others white (grid.hpp:527-534)
+    int32_t paint_white;         // 1: r = g = b = 255 as downloadHQ / downloadClassified set it (grid.hpp:527-529,558-560)
+};
+__global__ __launch_bounds__(256) void k_extract_keys(const GridParams g, const Tables t, const unsigned long long* __restrict__ stats,
+                                                      const uint64_t n_normals, const ExtractOpts opt, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t valid = 0;
@@ -1100,6 +1110,10 @@ __global__ __launch_bounds__(256) void k_extract_keys(const GridParams g, const 
         int32_t x, y, z;
         key_coords(key, x, y, z);
         valid = valid_coord(g, x, y, z) ? 1u : 0u;
+        if (valid && opt.min_count > 0.0) {
+            const long long cnt = (long long)stats[nid * kStatWords + SW_COUNT];
+            if ((double)(int)cnt < opt.min_count) valid = 0;  // int count against a double threshold, grid.hpp:561
+        }
         keys[j] = valid ? key : ~0ull;
         vals[j] = (uint32_t)nid;
     }
@@ -1118,8 +1132,8 @@ struct Row {  // = hfpf_row
 static_assert(sizeof(Row) == 64, "row is 64 bytes");
 
 __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const Tables t, const unsigned long long* __restrict__ stats,
-                                                      const uint64_t n_rows, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                      Row* __restrict__ rows)
+                                                      const uint64_t n_rows, const ExtractOpts opt, const uint64_t* __restrict__ keys,
+                                                      const uint32_t* __restrict__ vals, Row* __restrict__ rows)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rows) return;
@@ -1164,6 +1178,8 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
             r.rgb = (min(cr, 255u) << 16) | (min(cg, 255u) << 8) | min(cb, 255u);
         }
     }
+    if (opt.paint_white) r.rgb = 0x00FFFFFFu;
+    if (opt.classify_threshold >= 0) r.rgb = (int)r.count > opt.classify_threshold ? 0x00FF0000u : 0x00FFFFFFu;
     rows[j] = r;
 }
 

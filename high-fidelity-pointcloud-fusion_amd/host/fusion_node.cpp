@@ -27,6 +27,9 @@ struct hfpf_node {
     std::mutex frame_mtx;
     double clean_period_s = 5.0;
     bool final_clean = false;
+    bool write_variants = false;
+    hfpf_publish_fn publish = nullptr;  // ~pcl_fusion_node/processed_cloud_normals (node.cpp:158)
+    void* publish_user = nullptr;
     std::thread clean_thread;
     std::mutex cv_mtx;
     std::condition_variable cv;
@@ -80,6 +83,7 @@ void hfpf_node_default_params(hfpf_node_params* p)
     hfpf_default_config(&p->engine);
     p->clean_period_s = 5.0;  // node.cpp:323
     p->final_clean_on_process = 0;
+    p->write_variants = 0;
 }
 
 const char* hfpf_node_last_error(const hfpf_node* n) { return n ? n->err.c_str() : g_err.c_str(); }
@@ -99,6 +103,7 @@ int hfpf_node_create(const hfpf_node_params* p, hfpf_tf_lookup_fn tf, void* tf_u
     n->tf_user = tf_user;
     n->clean_period_s = p->clean_period_s;
     n->final_clean = p->final_clean_on_process != 0;
+    n->write_variants = p->write_variants != 0;
     hfpf_config cfg = p->engine;
     cfg.struct_size = sizeof cfg;
     memcpy(cfg.bbox, p->bounding_box, 6 * sizeof(double));
@@ -202,7 +207,40 @@ int hfpf_node_process(hfpf_node* n, hfpf_trigger_response* res)
     int rc = hfpf_extract(n->grid, &rows, &nr);  // grid_.downloadData, node.cpp:398
     if (rc == HFPF_OK) rc = hfpf_write_pcd(rows, nr, cloud_location.c_str());
     if (rc == HFPF_OK) rc = hfpf_write_meta_csv(rows, nr, meta_location.c_str());
+    if (rc == HFPF_OK && n->publish) n->publish(n->publish_user, rows, nr, n->fusion_frame.c_str());  // processed_cloud_, node.cpp:158
     hfpf_free_rows(rows);
+    if (rc == HFPF_OK && n->write_variants) {  // the reference's `#if 0` block, node.cpp:399-437
+        struct Variant {
+            const char* file;
+            double min_count;
+            int classify;
+            int white;
+        };
+        const Variant vs[] = {{"test_cloud_50.pcd", 50, -1, 1},   {"test_cloud_100.pcd", 100, -1, 1}, {"test_cloud_150.pcd", 150, -1, 1},
+                              {"test_cloud_200.pcd", 200, -1, 1}, {"test_cloud_250.pcd", 250, -1, 1}, {"test_cloud_300.pcd", 300, -1, 1},
+                              {"test_cloud_classified.pcd", 0, 100 /* kGoodPointsThreshold, grid.hpp:34 */, 0}};
+        for (const Variant& v : vs) {
+            hfpf_extract_opts o;
+            memset(&o, 0, sizeof o);
+            o.struct_size = sizeof o;
+            o.min_count = v.min_count;
+            o.classify_threshold = v.classify;
+            o.paint_white = v.white;
+            hfpf_row* vr = nullptr;
+            uint64_t vn = 0;
+            rc = hfpf_extract_filtered(n->grid, &o, &vr, &vn);  // filtered and colour-coded on the device
+            if (rc == HFPF_OK) rc = hfpf_write_pcd_xyzrgb(vr, vn, (n->directory_name + "/" + v.file).c_str(), 0, -1, 0);
+            hfpf_free_rows(vr);
+            if (rc != HFPF_OK) break;
+        }
+        if (rc == HFPF_OK) {  // download(PointXYZRGBNormal), grid.hpp:577-601
+            hfpf_row* vr = nullptr;
+            uint64_t vn = 0;
+            rc = hfpf_extract(n->grid, &vr, &vn);
+            if (rc == HFPF_OK) rc = hfpf_write_pcd(vr, vn, (n->directory_name + "/test_cloud_normals.pcd").c_str());
+            hfpf_free_rows(vr);
+        }
+    }
     if (rc != HFPF_OK) {
         const std::string m = rc == HFPF_ERR_IO ? "cannot write " + cloud_location + " / " + meta_location : std::string(hfpf_last_error(n->grid));
         set_res(res, false, m);
@@ -216,6 +254,14 @@ int hfpf_node_process(hfpf_node* n, hfpf_trigger_response* res)
     char m[200];
     snprintf(m, sizeof m, "saved %llu points", (unsigned long long)nr);
     set_res(res, true, std::string(m) + " to " + cloud_location);
+    return HFPF_OK;
+}
+
+int hfpf_node_set_publisher(hfpf_node* n, hfpf_publish_fn fn, void* user)
+{
+    if (!n) return HFPF_ERR_BAD_ARG;
+    n->publish = fn;
+    n->publish_user = user;
     return HFPF_OK;
 }
 

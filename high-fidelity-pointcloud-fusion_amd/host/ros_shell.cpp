@@ -41,6 +41,40 @@ struct Shell {
                            m->fields[2].offset, m->fields[3].offset, m->header.frame_id.c_str()};
         if (hfpf_node_on_point_cloud(node, &msg) < 0) ROS_ERROR("%s", hfpf_node_last_error(node));
     }
+    // ~pcl_fusion_node/processed_cloud_normals: the cloud ~process is about to save, as x y z rgb normal_x normal_y normal_z
+    // curvature (8 x f32 per point, the field list savePCDFileASCII writes for PointXYZRGBNormal, grid.hpp:485)
+    ros::Publisher* pub = nullptr;
+    static void publish(void* user, const hfpf_row* rows, uint64_t n, const char* frame_id)
+    {
+        Shell* s = static_cast<Shell*>(user);
+        if (!s->pub) return;
+        sensor_msgs::PointCloud2 m;
+        m.header.stamp = ros::Time::now();
+        m.header.frame_id = frame_id;
+        m.height = 1;
+        m.width = (uint32_t)n;
+        m.is_bigendian = false;
+        m.is_dense = true;
+        m.point_step = 32;
+        m.row_step = m.point_step * m.width;
+        const char* names[8] = {"x", "y", "z", "rgb", "normal_x", "normal_y", "normal_z", "curvature"};
+        for (int k = 0; k < 8; ++k) {
+            sensor_msgs::PointField f;
+            f.name = names[k];
+            f.offset = 4 * k;
+            f.datatype = sensor_msgs::PointField::FLOAT32;
+            f.count = 1;
+            m.fields.push_back(f);
+        }
+        m.data.resize((size_t)m.row_step);
+        for (uint64_t i = 0; i < n; ++i) {
+            float rec[8] = {rows[i].x, rows[i].y, rows[i].z, 0.f, rows[i].nx, rows[i].ny, rows[i].nz, 0.f};
+            const uint32_t rgba = 0xFF000000u | rows[i].rgb;
+            memcpy(&rec[3], &rgba, 4);
+            memcpy(&m.data[(size_t)i * 32], rec, 32);
+        }
+        s->pub->publish(m);
+    }
     template <int (*F)(hfpf_node*, hfpf_trigger_response*)>
     bool srv(std_srvs::TriggerRequest&, std_srvs::TriggerResponse& res)
     {
@@ -83,6 +117,7 @@ int main(int argc, char** argv)
     bool flag;
     if (pnh.getParam("fuse_color", flag) && flag) p.engine.flags |= HFPF_FLAG_FUSE_COLOR;
     if (pnh.getParam("pcl_shifted_covariance", flag) && flag) p.engine.flags |= HFPF_FLAG_PCL_SHIFTED_COV;
+    if (pnh.getParam("write_variants", flag) && flag) p.write_variants = 1;  // the files of the reference's `#if 0` block, node.cpp:399-437
     Shell shell;
     if (hfpf_node_create(&p, &Shell::lookup, &shell, &shell.node) != HFPF_OK) {
         ROS_FATAL("%s", hfpf_node_last_error(nullptr));
@@ -93,7 +128,9 @@ int main(int argc, char** argv)
     ros::ServiceServer s2 = pnh.advertiseService("start", &Shell::srv<hfpf_node_start>, &shell);                // node.cpp:155
     ros::ServiceServer s3 = pnh.advertiseService("stop", &Shell::srv<hfpf_node_stop>, &shell);                  // node.cpp:156
     ros::ServiceServer s4 = pnh.advertiseService("process", &Shell::srv<hfpf_node_process>, &shell);            // node.cpp:157
-    ros::Publisher pub = pnh.advertise<sensor_msgs::PointCloud2>("pcl_fusion_node/processed_cloud_normals", 1);  // node.cpp:158 (latent)
+    ros::Publisher pub = pnh.advertise<sensor_msgs::PointCloud2>("pcl_fusion_node/processed_cloud_normals", 1);  // node.cpp:158
+    shell.pub = &pub;  // latent in the reference (advertised, never published); here ~process publishes the cloud it saves
+    hfpf_node_set_publisher(shell.node, &Shell::publish, &shell);
     ros::Rate loop_rate(31);  // node.cpp:453
     while (ros::ok()) {
         ros::spinOnce();

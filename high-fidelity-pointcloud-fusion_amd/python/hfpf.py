@@ -56,6 +56,11 @@ class Config(C.Structure):
     ]
 
 
+class ExtractOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("classify_threshold", C.c_int32), ("min_count", C.c_double),
+                ("paint_white", C.c_int32), ("reserved0", C.c_int32)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "points_presented", "points_zclip_pass", "points_in_bbox", "points_buffered", "dep_pairs_tested",
@@ -76,7 +81,7 @@ ROW_DTYPE = np.dtype(
 # every symbol include/hfpf.h and include/hfpf_probe.h declare
 EXPORTS = [
     "hfpf_default_config", "hfpf_abi_version", "hfpf_create", "hfpf_destroy", "hfpf_last_error", "hfpf_get_dims",
-    "hfpf_integrate", "hfpf_integrate_device", "hfpf_is_dirty", "hfpf_clean", "hfpf_extract", "hfpf_free_rows",
+    "hfpf_integrate", "hfpf_integrate_device", "hfpf_is_dirty", "hfpf_clean", "hfpf_extract", "hfpf_extract_filtered", "hfpf_free_rows",
     "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_write_pcd_xyzrgb", "hfpf_write_pcd_binary", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
     "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
     "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
@@ -119,6 +124,7 @@ def lib():
     L.hfpf_is_dirty.argtypes = [vp]
     L.hfpf_clean.argtypes = [vp]
     L.hfpf_extract.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.hfpf_extract_filtered.argtypes = [vp, C.POINTER(ExtractOpts), C.POINTER(vp), C.POINTER(u64)]
     L.hfpf_free_rows.argtypes = [vp]
     L.hfpf_free_rows.restype = None
     L.hfpf_write_pcd.argtypes = [vp, u64, C.c_char_p]
@@ -288,6 +294,15 @@ class OccupancyGrid:
         rows = C.c_void_p()
         n = C.c_uint64()
         self._chk(lib().hfpf_extract(self._h, C.byref(rows), C.byref(n)))
+        return self._rows_out(rows, n)
+
+    def extract_filtered(self, min_count=0.0, classify_threshold=-1, paint_white=False):
+        """downloadHQ(threshold) / downloadClassified / download of the reference (grid.hpp:491-601): the same ordered
+        extract with the count filter and the colour coding done on the device."""
+        o = ExtractOpts(C.sizeof(ExtractOpts), int(classify_threshold), float(min_count), 1 if paint_white else 0, 0)
+        rows = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(lib().hfpf_extract_filtered(self._h, C.byref(o), C.byref(rows), C.byref(n)))
         return self._rows_out(rows, n)
 
     # -- multi-GPU --

@@ -10,17 +10,18 @@ import hfpf
 _LIB_PATH = os.path.join(hfpf.PKG_DIR, "host", "libhfpf_node.so")
 _lib = None
 
+PUBLISH_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p)
 TF_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_char), C.c_uint32)
 
 EXPORTS = ["hfpf_node_default_params", "hfpf_node_create", "hfpf_node_destroy", "hfpf_node_last_error", "hfpf_node_on_point_cloud",
            "hfpf_node_start", "hfpf_node_stop", "hfpf_node_reset", "hfpf_node_process", "hfpf_node_clean_now", "hfpf_node_grid",
-           "hfpf_node_get_stats"]
+           "hfpf_node_get_stats", "hfpf_node_set_publisher"]
 
 
 class Params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("fusion_frame", C.c_char_p), ("directory_name", C.c_char_p),
                 ("bounding_box", C.POINTER(C.c_double)), ("bounding_box_len", C.c_uint32), ("engine", hfpf.Config),
-                ("clean_period_s", C.c_double), ("final_clean_on_process", C.c_int32)]
+                ("clean_period_s", C.c_double), ("final_clean_on_process", C.c_int32), ("write_variants", C.c_int32)]
 
 
 class CloudMsg(C.Structure):
@@ -56,6 +57,7 @@ def lib():
         L.hfpf_node_grid.argtypes = [C.c_void_p]
         L.hfpf_node_grid.restype = C.c_void_p
         L.hfpf_node_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.hfpf_node_set_publisher.argtypes = [C.c_void_p, PUBLISH_FN, C.c_void_p]
         _lib = L
     return _lib
 
@@ -64,7 +66,7 @@ class FusionNode:
     """pointcloud_fusion_and_filter without ROS: params in, Trigger services and the cloud callback as methods."""
 
     def __init__(self, bounding_box, directory_name="./", fusion_frame="fusion_frame", tf_lookup=None, clean_period_s=0.0,
-                 final_clean_on_process=False, resolution=None, **caps):
+                 final_clean_on_process=False, resolution=None, write_variants=False, publisher=None, **caps):
         L = lib()
         p = Params()
         L.hfpf_node_default_params(C.byref(p))
@@ -78,7 +80,9 @@ class FusionNode:
             setattr(p.engine, k, v)
         p.clean_period_s = clean_period_s
         p.final_clean_on_process = 1 if final_clean_on_process else 0
+        p.write_variants = 1 if write_variants else 0
         self._tf_py = tf_lookup
+        self._pub_py = publisher
 
         def _tf(user, target, source, pose, err, cap):
             if self._tf_py is None:
@@ -98,6 +102,14 @@ class FusionNode:
         if rc != 0:
             self._h = None
             raise hfpf.HfpfError(rc, L.hfpf_node_last_error(None).decode())
+
+        def _pub(user, rows, n_rows, frame_id):  # the rows are only valid during the call: copy
+            arr = np.frombuffer((C.c_char * (n_rows * hfpf.ROW_DTYPE.itemsize)).from_address(rows), dtype=hfpf.ROW_DTYPE).copy() if n_rows else \
+                np.zeros(0, dtype=hfpf.ROW_DTYPE)
+            self._pub_py(arr, frame_id.decode())
+        self._pub_c = PUBLISH_FN(_pub)
+        if publisher is not None:
+            L.hfpf_node_set_publisher(self._h, self._pub_c, None)
 
     def close(self):
         if getattr(self, "_h", None):

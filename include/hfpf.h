@@ -152,6 +152,21 @@ int hfpf_clean(hfpf_handle* h);
  * extract (rows in lexicographic x,y,z order, engine-owned buffer) and the two file writers. */
 int hfpf_extract(hfpf_handle* h, hfpf_row** rows, uint64_t* n_rows);
 void hfpf_free_rows(hfpf_row* rows);
+/* The alternate extractors the reference keeps behind `#if 0` (node.cpp:399-437) as options of the same device-side scan:
+ *   downloadHQ(cloud, threshold)   grid.hpp:546-575   min_count = threshold (rows with count < threshold are dropped ON THE
+ *                                                      DEVICE, before the sort's compaction: they never reach the host), paint_white = 1
+ *   downloadClassified(cloud)      grid.hpp:512-544   classify_threshold = kGoodPointsThreshold = 100 (grid.hpp:34): count > 100
+ *                                                      -> red (g = b = 0), else white
+ *   download(XYZRGB / XYZRGBNormal) grid.hpp:491-510,577-601  all defaults (rgb stays 0 as a default-constructed PCL point)
+ * Row order is the same lexicographic (x,y,z) order.  opts == NULL is hfpf_extract. */
+typedef struct hfpf_extract_opts {
+    uint32_t struct_size;       /* = sizeof(hfpf_extract_opts) */
+    int32_t classify_threshold; /* < 0: off */
+    double min_count;           /* 0: keep all */
+    int32_t paint_white;        /* 1: rgb = 0x00FFFFFF */
+    int32_t reserved0;
+} hfpf_extract_opts;
+int hfpf_extract_filtered(hfpf_handle* h, const hfpf_extract_opts* opts, hfpf_row** rows, uint64_t* n_rows);
 /* <directory_name>/test_cloud.pcd (node.cpp:395): PCD v0.7 ASCII, FIELDS x y z rgb normal_x normal_y normal_z curvature */
 int hfpf_write_pcd(const hfpf_row* rows, uint64_t n_rows, const char* path);
 /* <directory_name>/meta.csv (node.cpp:396) with the header string of grid.hpp:462 */

@@ -24,6 +24,9 @@ typedef struct hfpf_node_params {
     hfpf_config engine;              /* every other engine knob; bbox is overwritten from bounding_box */
     double clean_period_s;           /* 5.0 = sleep(5) of cleanGrid (node.cpp:323); <= 0: no thread, use hfpf_node_clean_now */
     int32_t final_clean_on_process;  /* 0 = reference behaviour (process does not clean first, node.cpp:377-398) */
+    int32_t write_variants;          /* 1 = also write the files of the reference's `#if 0` block (node.cpp:399-437):
+                                        test_cloud_{50,100,150,200,250,300}.pcd (downloadHQ), test_cloud_classified.pcd,
+                                        test_cloud_normals.pcd; each a device-side filtered extract.  0 = reference behaviour */
 } hfpf_node_params;
 
 /* sensor_msgs/PointCloud2 as the decoder uses it (node.cpp:182-216): fields[0..3] = x,y,z,rgb. */
@@ -63,6 +66,13 @@ int hfpf_node_start(hfpf_node* n, hfpf_trigger_response* res);
 int hfpf_node_stop(hfpf_node* n, hfpf_trigger_response* res);
 int hfpf_node_reset(hfpf_node* n, hfpf_trigger_response* res);
 int hfpf_node_process(hfpf_node* n, hfpf_trigger_response* res);
+
+/* The latent publisher of the reference: it advertises `~pcl_fusion_node/processed_cloud_normals` (sensor_msgs/PointCloud2,
+ * node.cpp:138,158) and never publishes.  Here ~process hands the extracted PointXYZRGBNormal rows (the cloud it is about to
+ * save, in the fusion frame) to whoever registered; the ROS adapter (host/ros_shell.cpp) publishes them on that topic.
+ * The rows are only valid during the call. */
+typedef void (*hfpf_publish_fn)(void* user, const hfpf_row* rows, uint64_t n_rows, const char* frame_id);
+int hfpf_node_set_publisher(hfpf_node* n, hfpf_publish_fn fn, void* user);
 
 /* One iteration of cleanGrid (node.cpp:301-325): clean iff state_changed.  Returns 1 if a pass ran. */
 int hfpf_node_clean_now(hfpf_node* n);

@@ -133,3 +133,61 @@ def test_cpp_only_demo_matches_oracle(tmp_path, oracle_mod, hfpf_mod, synth_mod)
     assert np.abs(data[:, :3] - np.stack([ref["x"], ref["y"], ref["z"]], 1)).max() <= 1e-5
     assert np.array_equal(meta[:, 6], ref["count"])
     assert "saved %d points" % len(ref) in out.stdout
+
+
+def test_extract_variants_and_publisher(tmp_path, oracle_mod, hfpf_mod, synth_mod):
+    """The reference's alternate extractors (downloadHQ / downloadClassified / download, grid.hpp:491-601; used only inside
+    `#if 0`, node.cpp:399-437) as options of the device-side extract, against the oracle's rows filtered the same way; and the
+    latent ~pcl_fusion_node/processed_cloud_normals publisher (node.cpp:158) as a callback of the node shell."""
+    import hfpf_node
+    # 5 mm voxels with a 4 mm cylinder: counts reach the hundreds, so the reference's thresholds (50 .. 300, 100) bite
+    sc = scenes.Scene(12, 320, 240, 0.005, clean_every=3)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox, cylinder_radius=0.004)
+    ref = scenes.run(og, sc, "capture")
+    assert (ref["count"] >= 200).any() and (ref["count"] < 50).any() and (ref["count"] > 100).any()
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, cylinder_radius=0.004, **CAPS) as g:
+        full = scenes.run(g, sc, "integrate")
+        scenes.compare_rows(ref, full)
+        for thr in (50, 100.5, 150, 300):  # downloadHQ: `if (data->count < threshold) continue;` with a double threshold
+            got = g.extract_filtered(min_count=thr, paint_white=True)
+            want = ref[ref["count"].astype(np.float64) >= thr]
+            assert len(got) == len(want) < len(ref)
+            scenes.compare_rows(want, _with_rgb(got, 0))
+            assert (got["rgb"] == 0x00FFFFFF).all()
+        cls = g.extract_filtered(classify_threshold=100)  # downloadClassified: count > kGoodPointsThreshold -> red
+        assert len(cls) == len(ref)
+        assert np.array_equal(cls["rgb"], np.where(ref["count"] > 100, 0x00FF0000, 0x00FFFFFF).astype(np.uint32))
+        scenes.compare_rows(ref, _with_rgb(cls, 0))
+        plain = g.extract_filtered()  # download(XYZRGBNormal): the same rows as downloadData
+        assert plain.tobytes() == full.tobytes()
+    # the node shell: publisher callback + the `#if 0` files
+    seen = []
+    with hfpf_node.FusionNode(bounding_box=list(sc.bbox), directory_name=str(tmp_path), tf_lookup=lambda t, s: sc.poses[int(s)],
+                              resolution=sc.resolution, final_clean_on_process=True, write_variants=True,
+                              publisher=lambda rows, frame: seen.append((rows, frame)), cylinder_radius=0.004, **CAPS) as node:
+        node.start()
+        for f in range(sc.n_frames):
+            assert node.publish(sc.frame(f), 1, sc.W * sc.H, frame_id=str(f)) == 1
+            if (f + 1) % sc.clean_every == 0 and f + 1 < sc.n_frames:
+                node.clean_now()
+        rc, ok, msg = node.process()
+        assert ok, msg
+    assert len(seen) == 1 and seen[0][1] == "fusion_frame"
+    scenes.compare_rows(ref, seen[0][0])  # what was published is what was saved
+    for thr in (50, 100, 150, 200, 250, 300):
+        hdr, data = pcd_io.read_pcd_ascii(str(tmp_path / ("test_cloud_%d.pcd" % thr)))
+        want = ref[ref["count"] >= thr]
+        assert int(hdr["POINTS"]) == len(want) and hdr["FIELDS"] == "x y z rgb"
+        if len(want):
+            assert np.abs(data[:, :3] - np.stack([want["x"], want["y"], want["z"]], 1)).max() <= 1e-5
+    hdr, data = pcd_io.read_pcd_ascii(str(tmp_path / "test_cloud_classified.pcd"))
+    assert int(hdr["POINTS"]) == len(ref)
+    assert np.array_equal(data[:, 3].astype(np.uint64) & 0xFFFFFF, np.where(ref["count"] > 100, 0xFF0000, 0xFFFFFF))
+    hdr, data = pcd_io.read_pcd_ascii(str(tmp_path / "test_cloud_normals.pcd"))
+    assert int(hdr["POINTS"]) == len(ref) and np.allclose(data[:, 4:7], np.stack([ref["nx"], ref["ny"], ref["nz"]], 1), rtol=1e-7, atol=0)
+
+
+def _with_rgb(rows, value):
+    out = rows.copy()
+    out["rgb"] = value
+    return out
