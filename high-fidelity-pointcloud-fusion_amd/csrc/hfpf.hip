@@ -50,15 +50,17 @@ struct StageSlot {  // pose / frame-id staging for one in-flight integrate call
 };
 
 struct FrameSlot {  // host-frame staging (pinned + device)
-    void* h = nullptr;
+    void* h = nullptr;       // pinned bounce buffer (hfpf_integrate only; hfpf_integrate_pinned copies from the caller's memory)
+    size_t cap_h = 0;
     void* d = nullptr;
     size_t cap = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;    // main stream: the kernels that read d have finished
+    hipEvent_t copied = nullptr;  // copy stream: the upload into d has finished
     bool pending = false;
 };
 
 constexpr int kStageSlots = 8;
-constexpr int kFrameSlots = 2;
+constexpr int kFrameSlots = 8;  // uploads run ahead of the kernels by up to this many frames
 
 }  // namespace
 
@@ -68,6 +70,7 @@ struct hfpf_handle {
     GridParams g;
     Tables t;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // host-frame uploads, overlapped with the kernels of earlier frames
     std::string err;
     std::vector<void*> allocs;
     uint64_t device_bytes = 0;
@@ -921,6 +924,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         for (void* p : h->allocs) (void)hipFree(p);
         if (h->h_ctr) (void)hipHostFree(h->h_ctr);
         if (h->h_log_ctr) (void)hipHostFree(h->h_log_ctr);
+        if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         delete h;
         return rc;
@@ -933,6 +937,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
     if (cfg->device < 0 || cfg->device >= ndev) return bail(fail(h, HFPF_ERR_BAD_CONFIG, "device %d out of range (%d devices)", cfg->device, ndev));
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e)));
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+    if ((e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
     if ((e = hipHostMalloc((void**)&h->h_ctr, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail(fail(h, HFPF_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)));
     memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));
@@ -991,6 +996,11 @@ int hfpf_destroy(hfpf_handle* h)
         if (f.h) (void)hipHostFree(f.h);
         if (f.d) (void)hipFree(f.d);
         if (f.done) (void)hipEventDestroy(f.done);
+        if (f.copied) (void)hipEventDestroy(f.copied);
+    }
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamDestroy(h->copy_stream);
     }
     for (auto& pr : h->ev_pending) {
         (void)hipEventDestroy(pr.first);
@@ -1026,12 +1036,12 @@ int hfpf_integrate_device(hfpf_handle* h, const void* dev_base, uint32_t n_frame
     return integrate_device_locked(h, dev_base, n_frames, frame_stride, n_points, point_step, off_x, off_y, off_z, off_rgb, poses, frame_ids);
 }
 
-int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
-                   uint32_t off_rgb, const double pose[12])
+// One host frame: upload on the copy stream into the next slot of the device staging ring, integrate on the main stream
+// behind it.  The upload of frame k+1 overlaps the kernels of frame k; `bounce` = copy the caller's (pageable) buffer into the
+// slot's pinned buffer first, so that the caller's memory is free again when the call returns.
+static int integrate_host_locked(hfpf_handle* h, const void* base, bool bounce, uint32_t n_points, uint32_t point_step, uint32_t off_x,
+                                 uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double pose[12])
 {
-    if (!h) return HFPF_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(h->mtx);
-    HIPCHK(h, hipSetDevice(h->cfg.device));
     if (!base || !pose) return fail(h, HFPF_ERR_BAD_ARG, "integrate: null buffer or pose");
     if (int rc0 = check_usable(h)) return rc0;
     if (n_points == 0) {
@@ -1043,28 +1053,83 @@ int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t
     const size_t bytes = (size_t)n_points * point_step;
     FrameSlot& f = h->fslot[h->fslot_next];
     h->fslot_next = (h->fslot_next + 1) % kFrameSlots;
-    if (f.pending) {
+    if (f.pending) {  // the kernels that read this slot's device buffer (kFrameSlots frames ago)
         HIPCHK(h, hipEventSynchronize(f.done));
         f.pending = false;
     }
     if (!f.done) HIPCHK(h, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    if (!f.copied) HIPCHK(h, hipEventCreateWithFlags(&f.copied, hipEventDisableTiming));
+    const size_t cap = (bytes + 4095) & ~(size_t)4095;
     if (f.cap < bytes) {
-        if (f.h) {
-            HIPCHK(h, hipHostFree(f.h));
-            HIPCHK(h, hipFree(f.d));
-            f.h = f.d = nullptr;
-        }
-        const size_t cap = (bytes + 4095) & ~(size_t)4095;
-        HIPCHK(h, hipHostMalloc(&f.h, cap, hipHostMallocDefault));
+        if (f.d) HIPCHK(h, hipFree(f.d));
+        f.d = nullptr;
         HIPCHK(h, hipMalloc(&f.d, cap));
         f.cap = cap;
     }
-    memcpy(f.h, base, bytes);  // the caller's buffer is free again when this call returns
-    HIPCHK(h, hipMemcpyAsync(f.d, f.h, bytes, hipMemcpyHostToDevice, h->stream));
+    const void* src = base;
+    if (bounce) {
+        if (f.cap_h < bytes) {
+            if (f.h) HIPCHK(h, hipHostFree(f.h));
+            f.h = nullptr;
+            HIPCHK(h, hipHostMalloc(&f.h, cap, hipHostMallocDefault));
+            f.cap_h = cap;
+        }
+        memcpy(f.h, base, bytes);  // the caller's buffer is free again when this call returns
+        src = f.h;
+    }
+    HIPCHK(h, hipMemcpyAsync(f.d, src, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(f.copied, h->copy_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, f.copied, 0));
     int rc = integrate_device_locked(h, f.d, 1, 0, n_points, point_step, off_x, off_y, off_z, off_rgb, pose, nullptr);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(f.done, h->stream));
     f.pending = true;
+    return HFPF_OK;
+}
+
+int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                   uint32_t off_rgb, const double pose[12])
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return integrate_host_locked(h, base, true, n_points, point_step, off_x, off_y, off_z, off_rgb, pose);
+}
+
+int hfpf_integrate_pinned(hfpf_handle* h, const void* pinned_base, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                          uint32_t off_z, uint32_t off_rgb, const double pose[12])
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (pinned_base) {
+        hipPointerAttribute_t attr;
+        const hipError_t e = hipPointerGetAttributes(&attr, pinned_base);
+        if (e != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return fail(h, HFPF_ERR_BAD_ARG, "integrate_pinned: the buffer is not page-locked host memory (hfpf_host_alloc / hipHostRegister); use hfpf_integrate");
+        }
+    }
+    return integrate_host_locked(h, pinned_base, false, n_points, point_step, off_x, off_y, off_z, off_rgb, pose);
+}
+
+int hfpf_host_alloc(hfpf_handle* h, uint64_t bytes, void** host_ptr)
+{
+    if (!h || !host_ptr) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipHostMalloc(host_ptr, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+    return HFPF_OK;
+}
+
+int hfpf_host_free(hfpf_handle* h, void* host_ptr)
+{
+    if (!h) return HFPF_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipHostFree(host_ptr));
     return HFPF_OK;
 }
 

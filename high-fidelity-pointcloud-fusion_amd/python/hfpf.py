@@ -81,7 +81,7 @@ ROW_DTYPE = np.dtype(
 # every symbol include/hfpf.h and include/hfpf_probe.h declare
 EXPORTS = [
     "hfpf_default_config", "hfpf_abi_version", "hfpf_create", "hfpf_destroy", "hfpf_last_error", "hfpf_get_dims",
-    "hfpf_integrate", "hfpf_integrate_device", "hfpf_is_dirty", "hfpf_clean", "hfpf_extract", "hfpf_extract_filtered", "hfpf_free_rows",
+    "hfpf_integrate", "hfpf_integrate_pinned", "hfpf_host_alloc", "hfpf_host_free", "hfpf_integrate_device", "hfpf_is_dirty", "hfpf_clean", "hfpf_extract", "hfpf_extract_filtered", "hfpf_free_rows",
     "hfpf_write_pcd", "hfpf_write_meta_csv", "hfpf_write_pcd_xyzrgb", "hfpf_write_pcd_binary", "hfpf_clear", "hfpf_sync", "hfpf_get_counters", "hfpf_get_occupied",
     "hfpf_device_alloc", "hfpf_device_free", "hfpf_device_upload", "hfpf_kernel_timing", "hfpf_get_kernel_time",
     "hfpf_probe_points", "hfpf_probe_normals", "hfpf_probe_project", "hfpf_probe_trig",
@@ -121,6 +121,9 @@ def lib():
     L.hfpf_get_dims.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
     L.hfpf_integrate.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp]
     L.hfpf_integrate_device.argtypes = [vp, vp, u32, u64, u32, u32, u32, u32, u32, u32, vp, vp]
+    L.hfpf_integrate_pinned.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp]
+    L.hfpf_host_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.hfpf_host_free.argtypes = [vp, vp]
     L.hfpf_is_dirty.argtypes = [vp]
     L.hfpf_clean.argtypes = [vp]
     L.hfpf_extract.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
@@ -261,6 +264,22 @@ class OccupancyGrid:
         if n_points is None:
             n_points = buf.nbytes // point_step
         self._chk(lib().hfpf_integrate(self._h, _p(buf), n_points, point_step, off_x, off_y, off_z, off_rgb, _p(pose)))
+
+    def host_alloc(self, nbytes):
+        """Page-locked host memory as a uint8 numpy view (free with host_free(view))."""
+        p = C.c_void_p()
+        self._chk(lib().hfpf_host_alloc(self._h, nbytes, C.byref(p)))
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=np.uint8)
+
+    def host_free(self, view):
+        self._chk(lib().hfpf_host_free(self._h, C.c_void_p(view.ctypes.data)))
+
+    def integrate_pinned(self, buf, pose, n_points=None, point_step=16, off_x=0, off_y=4, off_z=8, off_rgb=12):
+        """One frame straight from page-locked memory (a view from host_alloc): asynchronous, no bounce copy."""
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        if n_points is None:
+            n_points = buf.nbytes // point_step
+        self._chk(lib().hfpf_integrate_pinned(self._h, C.c_void_p(buf.ctypes.data), n_points, point_step, off_x, off_y, off_z, off_rgb, _p(pose)))
 
     def integrate_device(self, dev_ptr, n_frames, frame_stride, n_points, poses, frame_ids=None, point_step=16, off_x=0,
                          off_y=4, off_z=8, off_rgb=12):

@@ -135,6 +135,15 @@ int hfpf_get_dims(const hfpf_handle* h, int32_t dims[3], double* resolution);
 int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x,
                    uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double pose_3x4[12]);
 
+/* The same for a frame in PAGE-LOCKED host memory (hfpf_host_alloc below, or hipHostRegister by the caller): no bounce copy; the
+ * upload runs on the engine's copy stream and overlaps the kernels of earlier frames, the call returns at once.  The buffer must
+ * stay untouched until the next hfpf_sync / hfpf_clean / hfpf_extract of this handle (all of which wait for queued work).
+ * hfpf_integrate itself uploads the same way after copying the caller's buffer into pinned staging. */
+int hfpf_integrate_pinned(hfpf_handle* h, const void* pinned_base, uint32_t n_points, uint32_t point_step, uint32_t off_x,
+                          uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double pose_3x4[12]);
+int hfpf_host_alloc(hfpf_handle* h, uint64_t bytes, void** host_ptr); /* page-locked host memory */
+int hfpf_host_free(hfpf_handle* h, void* host_ptr);
+
 /* Same path for frames already resident in HBM: n_frames frames, frame f at dev_base + f*frame_stride,
  * poses = n_frames*12 f64 in HOST memory, frame_ids = n_frames ids in HOST memory or NULL (auto).
  * One launch covers the whole batch; asynchronous on the engine's stream. */

@@ -157,3 +157,28 @@ def test_concurrent_callers_are_serialised_and_order_free(hfpf_mod, synth_mod):
         for d in devs:
             b.device_free(d)
     assert ref.tobytes() == got.tobytes()
+
+
+def test_pinned_host_entry_point_matches_bounce_path(hfpf_mod, synth_mod):
+    """hfpf_integrate_pinned (upload straight from page-locked memory on the copy stream, asynchronous) gives the same bytes as
+    hfpf_integrate (bounce copy) frame by frame, with more frames in flight than the staging ring has slots; a pageable buffer
+    is refused."""
+    sc = scenes.Scene(12, 160, 120, 0.001, fx=615.0, clean_every=5)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as a:
+        ref = scenes.run(a, sc, "integrate")
+    fb = sc.W * sc.H * 16
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as g:
+        pinned = g.host_alloc(sc.n_frames * fb)
+        for f in range(sc.n_frames):
+            pinned[f * fb:(f + 1) * fb] = sc.frame(f)
+        for ev in sc.schedule():
+            if ev[0] == "integrate":
+                g.integrate_pinned(pinned[ev[1] * fb:(ev[1] + 1) * fb], sc.poses[ev[1]])
+            else:
+                g.clean()
+        got = g.extract()
+        with pytest.raises(hfpf_mod.HfpfError) as e:
+            g.integrate_pinned(sc.frame(0), sc.poses[0])  # an ordinary numpy buffer
+        assert e.value.code == -2 and "page-locked" in str(e.value)
+        g.host_free(pinned)
+    assert got.tobytes() == ref.tobytes()
