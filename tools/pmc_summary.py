@@ -1,84 +1,88 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes (one counter set per pass, as MI355X_MICROARCH.md prescribes) for the integrate
-hot path: k_integrate (decode/clip/transform/insert/bin) + k_update (per-brick LDS accumulation).
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh (one counter set per pass, as MI355X_MICROARCH.md prescribes) for
+the integrate hot path: k_integrate (decode / clip / transform / insert / park) + k_update (per-brick LDS accumulation).
 
-usage: python tools/pmc_summary.py gpurun_out pmc3 profiles/r01_pmc_hot_path [frames_per_launch=150]
-Reads gpurun_out/<prefix>_<COUNTERS>/*/*_counter_collection.csv written by
-`rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 600 --warmup 5 ...`
-and writes <out>.json / <out>.md with per-launch values (one launch = one hfpf_integrate_device call of 150 frames,
-bench.py's default: one clean epoch per call).
-FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction: FETCH_SIZE reports half the bytes of a wide (16 B/lane)
-coalesced stream, so 8 B per streamed 16-byte record is added (the frame read in k_integrate, the bin read-back in
+usage: python tools/pmc_summary.py gpurun_out/<prefix> profiles/r02_pmc_hot_path
+
+Each pass ran `bench.py --repeats 1 --warmup 0 --cpu-sample 0 --host-path-frames 0`: the 1000-frame configs[1] stream, one
+hfpf_integrate_device call per clean epoch.  k_integrate dispatches: #0 = the first epoch (everything is buffered, no dependant
+exists yet), #1..#5 = steady state, 150 frames each (#6 is the 100-frame tail and is left out of the per-launch means);
+k_update dispatches #0..#4 belong to the steady launches #1..#5.
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of a wide
+(16 B/lane) coalesced stream, so 8 B per streamed 16-byte record are added (the frame read in k_integrate, the bin read-back in
 k_update); narrower scattered reads are uncalibrated.
+Writes <out>.json (read by bench.py, with the hash of the kernel sources it was taken on) and <out>.md.
 """
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FRAMES_PER_LAUNCH = 150
-NPTS_PER_LAUNCH = FRAMES_PER_LAUNCH * 640 * 480
+NPTS = 640 * 480
+KERNEL_SOURCES = ("kernels.hpp", "tables.hpp", "stats.hpp", "geometry.hpp", "det_math.hpp", "hfpf.hip")
 
 
-def load(root, prefix, name):
-    fs = glob.glob("%s/%s_%s/*/*counter_collection.csv" % (root, prefix, name)) + glob.glob("%s/%s_%s/*counter_collection.csv" % (root, prefix, name))
-    per = collections.defaultdict(list)
-    if not fs:
-        return per
-    for r in csv.DictReader(open(fs[0])):
-        k = r["Kernel_Name"]
-        which = "A" if "k_integrate" in k else ("B" if "k_update" in k else None)
-        if which:
-            per[(which, r["Counter_Name"])].append(float(r["Counter_Value"]))
+def source_sha():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "high-fidelity-pointcloud-fusion_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load(prefix):
+    per = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> counter -> dispatch id -> value
+    for f in sorted(glob.glob(prefix + "_*/**/*counter_collection.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            which = "k_integrate" if "k_integrate" in k else ("k_update" if "k_update" in k else None)
+            if which:
+                per[which][r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
     return per
 
 
+def series(per, kernel, counter):
+    d = per[kernel].get(counter, {})
+    return [d[i] for i in sorted(d)]
+
+
 def main():
-    global FRAMES_PER_LAUNCH, NPTS_PER_LAUNCH
-    root, prefix, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    if len(sys.argv) > 4:
-        FRAMES_PER_LAUNCH = int(sys.argv[4])
-        NPTS_PER_LAUNCH = FRAMES_PER_LAUNCH * 640 * 480
-    vals = {}
-    for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum", "TCC_HIT_sum_TCC_MISS_sum"):
-        vals.update(load(root, prefix, name))
-    avg = lambda v: sum(v) / max(len(v), 1)
-    # k_integrate dispatches for --steps 600 --warmup 5 --clean-every 150: [warm-up, first epoch x n_first, steady x rest];
-    # k_update only exists in steady state
-    n_first = max(1, 150 // FRAMES_PER_LAUNCH)
-    steady_a = lambda v: v[1 + n_first:] if len(v) > 1 + n_first else v[-1:]
-    first_a = lambda v: v[1:1 + n_first] if len(v) > 1 + n_first else v[:1]
-    res = {"points_per_launch": NPTS_PER_LAUNCH, "frames_per_launch": FRAMES_PER_LAUNCH,
-           "source": "rocprofv3 --pmc, separate passes, bench.py --steps 600 --warmup 5"}
-    get = lambda w, c, sel: avg(sel(vals.get((w, c), [0])))
-    for phase, sel_a, with_b in (("steady_state_after_first_clean", steady_a, True), ("first_epoch_buffer_only", first_a, False)):
-        fa = get("A", "FETCH_SIZE", sel_a) * 1024
-        wa = get("A", "WRITE_SIZE", sel_a) * 1024
-        aa = get("A", "TCC_EA0_ATOMIC_sum", sel_a)
-        ident = lambda v: v
-        fb = get("B", "FETCH_SIZE", ident) * 1024 if with_b else 0.0
-        wb = get("B", "WRITE_SIZE", ident) * 1024 if with_b else 0.0
-        ab = get("B", "TCC_EA0_ATOMIC_sum", ident) if with_b else 0.0
-        in_bbox = 0.83 * NPTS_PER_LAUNCH
-        corr = 0.5 * 16 * NPTS_PER_LAUNCH + (0.5 * 16 * in_bbox if with_b else 0.0)
+    prefix, out = sys.argv[1], sys.argv[2]
+    per = load(prefix)
+    mean = lambda v: sum(v) / len(v) if v else 0.0
+    in_bbox_frac = 0.826  # points_in_bbox / points_presented of the bench stream (bench.py counters)
+    pts = FRAMES_PER_LAUNCH * NPTS
+    res = {"source_sha": source_sha(), "points_per_launch": pts, "frames_per_launch": FRAMES_PER_LAUNCH,
+           "source": "rocprofv3 --pmc, separate passes (tools/pmc_passes.sh), bench.py --repeats 1 --warmup 0"}
+    for phase, sel_a, sel_b in (("first_epoch_buffer_only", lambda v: v[:1], None),
+                                ("steady_state_after_first_clean", lambda v: v[1:6], lambda v: v[:5])):
+        ga = lambda c: mean(sel_a(series(per, "k_integrate", c)))
+        gb = (lambda c: mean(sel_b(series(per, "k_update", c)))) if sel_b else (lambda c: 0.0)
+        fa, wa, aa = ga("FETCH_SIZE") * 1024, ga("WRITE_SIZE") * 1024, ga("TCC_EA0_ATOMIC_sum")
+        fb, wb, ab = gb("FETCH_SIZE") * 1024, gb("WRITE_SIZE") * 1024, gb("TCC_EA0_ATOMIC_sum")
+        corr = 0.5 * 16 * pts + (0.5 * 16 * in_bbox_frac * pts if sel_b else 0.0)
         traffic = fa + fb + corr + wa + wb
+        hit = lambda g: g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1.0)
         res[phase] = {
-            "k_integrate": {"fetch_bytes_raw": fa, "write_bytes": wa, "atomic_requests": aa,
-                            "l2_hit_rate": get("A", "TCC_HIT_sum", sel_a) / max(get("A", "TCC_HIT_sum", sel_a) + get("A", "TCC_MISS_sum", sel_a), 1)},
-            "k_update": {"fetch_bytes_raw": fb, "write_bytes": wb, "atomic_requests": ab,
-                         "l2_hit_rate": (get("B", "TCC_HIT_sum", ident) / max(get("B", "TCC_HIT_sum", ident) + get("B", "TCC_MISS_sum", ident), 1)) if with_b else None},
+            "k_integrate": {"fetch_bytes_raw": fa, "write_bytes": wa, "atomic_requests": aa, "l2_hit_rate": hit(ga)},
+            "k_update": {"fetch_bytes_raw": fb, "write_bytes": wb, "atomic_requests": ab, "l2_hit_rate": hit(gb) if sel_b else None},
             "fetch_correction_bytes": corr,
             "atomic_requests": aa + ab,
             "traffic_bytes_per_launch": traffic,
-            "traffic_bytes_per_point": traffic / NPTS_PER_LAUNCH,
-            "algorithmic_bytes_per_launch": 32 * NPTS_PER_LAUNCH,
+            "traffic_bytes_per_point": traffic / pts,
+            "algorithmic_bytes_per_launch": 32 * pts,
         }
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
         f.write("# Integrate hot path: memory-side counters (rocprofv3 --pmc, one counter set per pass)\n\n")
+        f.write("Kernel sources `%s` (bench.py attaches these numbers only to a build with the same hash).\n" % res["source_sha"])
         f.write("Per launch = one `hfpf_integrate_device` call of %d frames = %d points. FETCH_SIZE corrected per MI355X_MICROARCH.md (HBM):\n"
-                "+8 B per streamed 16-byte record (gfx950 tallies wide coalesced reads at half); scattered 4-8 B table reads are uncalibrated.\n\n" % (FRAMES_PER_LAUNCH, NPTS_PER_LAUNCH))
+                "+8 B per streamed 16-byte record (gfx950 tallies wide coalesced reads at half); scattered 4-8 B table reads are uncalibrated.\n\n" % (FRAMES_PER_LAUNCH, pts))
         f.write("| phase | kernel | FETCH raw | WRITE | atomic requests | L2 hit rate |\n|---|---|---|---|---|---|\n")
         for phase in ("first_epoch_buffer_only", "steady_state_after_first_clean"):
             for k in ("k_integrate", "k_update"):
@@ -92,12 +96,6 @@ def main():
             r = res[phase]
             f.write("| %s | %.3f GB | %.0f | %.3f GB | %.2f M |\n" % (phase, r["traffic_bytes_per_launch"] / 1e9, r["traffic_bytes_per_point"],
                                                                  r["algorithmic_bytes_per_launch"] / 1e9, r["atomic_requests"] / 1e6))
-        st = res["steady_state_after_first_clean"]
-        f.write("\nReading: with the brick-binned update a steady-state launch issues %.1f M memory-side atomics (bin reservations + one flush per\n"
-                "record per brick) instead of one per (point, dependant) pair (`r01_pmc_k_integrate.md`, the earlier form, kept for comparison:\n"
-                "41 M atomics and 4.9 GB per 50 frames), and moves %.0f B per point.  `k_update` is served mostly from L2 (brick-local dependant\n"
-                "lists), `k_integrate` by sector fills for its 4-8-byte table lookups plus the streamed frame read and bin write.\n"
-                % (st["atomic_requests"] / 1e6, st["traffic_bytes_per_point"]))
     print(open(out + ".md").read())
 
 
