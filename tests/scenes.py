@@ -52,13 +52,15 @@ XYZ_TOL = 1e-5  # north_star: fused XYZ within 1e-5
 
 
 def error_report(ref, got):
-    """Largest deviations of the float columns (engine vs oracle), for the tolerance ledger in DESIGN.md."""
-    out = {}
-    for f in ("x", "y", "z", "mean_dist", "sdx", "sdy", "sdz", "sd_dist"):
+    """Largest deviations of the float columns (engine vs oracle), for the tolerance ledger in DESIGN.md: absolute, and
+    relative where the reference value is well above its own rounding noise."""
+    out = {"rows": int(len(ref))}
+    floors = {"x": 1e-3, "y": 1e-3, "z": 1e-3, "mean_dist": 1e-6, "sdx": 1e-9, "sdy": 1e-9, "sdz": 1e-9, "sd_dist": 1e-10}
+    for f, floor in floors.items():
         a, b = ref[f].astype(np.float64), got[f].astype(np.float64)
         d = np.abs(a - b)
         out[f + "_abs"] = float(d.max(initial=0.0))
-        big = np.abs(a) > 1e-12  # relative error only where the value is not itself rounding noise
+        big = np.abs(a) > floor
         out[f + "_rel"] = float((d[big] / np.abs(a[big])).max(initial=0.0))
     return out
 
@@ -80,14 +82,19 @@ def compare_rows(ref, got, normals_exact=True):
     for f in ("x", "y", "z"):
         d = np.abs(ref[f].astype(np.float64) - got[f].astype(np.float64))
         assert d.max(initial=0.0) <= XYZ_TOL, "fused %s differs by %.3g" % (f, d.max())
-    # meta.csv columns: the reference prints 6 significant digits of float Welford recurrences whose own
-    # rounding noise is ~1e-4 relative; compare loosely (documented in DESIGN.md).
-    for f in ("mean_dist",):
-        assert np.allclose(ref[f], got[f], rtol=1e-4, atol=1e-9), f
-    for f in ("sdx", "sdy", "sdz", "sd_dist"):
-        assert np.allclose(ref[f], got[f], rtol=5e-2, atol=2e-10), "%s max abs diff %.3g" % (
+    # meta.csv columns (the reference prints them with 6 significant digits).  Measured over every comparison of the GPU suite
+    # (63 scenes, up to 1.8 M rows): mean_dist within 4.7e-6 relative; sd_dist within 6e-4 relative;
+    # sdx/sdy/sdz within 1.6e-10 m^2 absolute.  The per-axis variances differ by the quantisation of the reference's f32
+    # projections (ulp 6e-8 m on coordinates near 1 m against deviations of ~3e-4 m), which the engine's exact moments of the
+    # projection parameter do not contain: an absolute error, ~1e-3 of a variance along the normal (1e-7 m^2).
+    assert np.allclose(ref["mean_dist"], got["mean_dist"], rtol=2e-5, atol=1e-10), "mean_dist"
+    assert np.allclose(ref["sd_dist"], got["sd_dist"], rtol=1e-3, atol=1e-12), "sd_dist max abs diff %.3g" % (
+        np.abs(ref["sd_dist"].astype(np.float64) - got["sd_dist"]).max(initial=0.0))
+    for f in ("sdx", "sdy", "sdz"):
+        assert np.allclose(ref[f], got[f], rtol=1e-3, atol=2e-10), "%s max abs diff %.3g" % (
             f, np.abs(ref[f].astype(np.float64) - got[f]).max(initial=0.0))
     import os
     if os.environ.get("HFPF_ERR_REPORT"):
         with open(os.environ["HFPF_ERR_REPORT"], "a") as fh:
-            fh.write("%d rows %r\n" % (len(ref), error_report(ref, got)))
+            import json
+            fh.write(json.dumps(error_report(ref, got)) + "\n")
