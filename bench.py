@@ -77,19 +77,28 @@ def make_stream(pose_seed, n_frames):
     return np.stack([S.pose(pose_seed, f, 30.0, 0.05) for f in range(n_frames)]).reshape(n_frames, 12)
 
 
-def cpu_baseline(poses, seed, n_sample, all_cores=False):
+def cpu_baseline(poses, seed, n_sample, variant="faithful"):
     """The CPU oracle (kind "port": the reference itself cannot be built here) timed on the first n_sample frames of the
     same stream: a clean half-way (so the second half exercises the dependant updates of grid.hpp:244-277 like the
-    steady state of the full run) and a final clean.  all_cores=False is the faithful single-threaded restatement (the
-    reference's OpenMP pragmas are commented out); all_cores=True is the OpenMP variant of the same work (sharded
-    voxel store, oracle/hfpf_oracle.cpp capture_mt/clean_mt) on the host cores this process may use."""
+    steady state of the full run) and a final clean.  Variants:
+      faithful   one thread (the reference's OpenMP pragmas are commented out), the reference's storage: a dense array of 16-byte
+                 voxels over the whole box (grid.hpp:626; 16 GB of address space at 1 m^3 @ 1 mm, touched sparsely) and
+                 buffer.reserve(1000) per new voxel (grid.hpp:228); falls back to the hash map when the array cannot be allocated
+      sparse     one thread, hash map of touched cells, no reserve (what the 10^10-cell configs need)
+      all_cores  OpenMP over points and clean candidates, voxel store sharded 256 ways (oracle capture_mt / clean_mt)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle  # only the cpu_baseline leg touches the oracle
 
     cores = 1
+    all_cores = variant == "all_cores"
     if all_cores:  # the GPU box gives one GPU a share of 16 host cores
         cores = oracle.set_threads(min(len(os.sched_getaffinity(0)), int(os.environ.get("HFPF_CPU_THREADS", "16"))))
-    og = oracle.OracleGrid(resolution=RES, bbox=BBOX)
+    kw = dict(dense=True, reserve=1000) if variant == "faithful" else {}
+    og = oracle.OracleGrid(resolution=RES, bbox=BBOX, **kw)
+    storage = "hash map of touched cells, no reserve"
+    if variant == "faithful":
+        storage = ("dense (dim+1)^3 voxel array + reserve(1000) per voxel, as the reference" if og.is_dense else
+                   "hash map of touched cells + reserve(1000) (the dense array could not be allocated)")
     capture, clean = (og.capture_mt, og.clean_mt) if all_cores else (og.capture, og.clean)
     frames = [S.frame(seed, f, W, H, poses[f].reshape(3, 4)) for f in range(n_sample)]
     half = max(1, n_sample // 2)
@@ -103,8 +112,7 @@ def cpu_baseline(poses, seed, n_sample, all_cores=False):
     og.close()
     how = ("OpenMP over points and clean candidates, voxel store sharded 256 ways" if all_cores else "single thread")
     return {"value": round(n_sample * NPTS / dt / 1e6, 4), "unit": "Mpts/s", "cores": cores, "kind": "port",
-            "sample": "first %d frames of the same stream, clean after frame %d and at the end, %s, sparse-storage "
-                      "restatement without the reference's 24 kB reserve per voxel (%.1f s)" % (n_sample, half, how, dt)}
+            "sample": "first %d frames of the same stream, clean after frame %d and at the end, %s, %s (%.1f s)" % (n_sample, half, how, storage, dt)}
 
 
 def claim_stdout():
@@ -141,7 +149,8 @@ def main():
     ap.add_argument("--clean-every-steps", type=int, default=3, help="clean pass every this many steps (3 x 50 frames = 150 frames ~ 5 s at 30 Hz) + final clean")
     ap.add_argument("--repeats", type=int, default=5, help="timed passes over the K-step stream (median reported)")
     ap.add_argument("--frames-per-call", type=int, default=0, help="frames handed to one hfpf_integrate_device call (0 = one clean epoch)")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle, sparse and all-cores variants (0 = skip all CPU legs)")
+    ap.add_argument("--cpu-sample-faithful", type=int, default=8, help="frames timed on the faithful variant (dense voxel array + reserve(1000): ~3 s per frame)")
     ap.add_argument("--write-dir", default=None, help="also time writing test_cloud.pcd (ASCII + binary) and meta.csv there")
     ap.add_argument("--host-path-frames", type=int, default=200, help="frames also pushed through the host-buffer entry point (0 = skip)")
     ap.add_argument("--allow-host-staged", action="store_true", help="rehearsals with several ranks on ONE GPU: fall back to the gloo host-staged transport when RCCL cannot form a communicator")
@@ -370,8 +379,9 @@ def main():
                                        "frac": round(atomic_req / avg_launch_s / 1e9 / (1300.0 / 64.0), 4) if atomic_req and avg_launch_s > 0 else None}},
         }
         if args.cpu_sample > 0 and world == 1:  # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen))
-            out["cpu_baseline_all_cores"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen), all_cores=True)
+            out["cpu_baseline"] = cpu_baseline(poses, seed, max(2, min(args.cpu_sample_faithful, args.cpu_sample, n_gen)), "faithful")
+            out["cpu_baseline_sparse"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen), "sparse")
+            out["cpu_baseline_all_cores"] = cpu_baseline(poses, seed, min(args.cpu_sample, n_gen), "all_cores")
             out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)  # informational; vs_baseline stays null (no published number)
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()

@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -283,6 +284,8 @@ struct Config {  // mirrored by oracle.py
     int32_t reserve;         // buffer.reserve(n) on first touch (reference: 1000, grid.hpp:228); 0 = off
     int32_t pcl_shifted_cov; // 0 = PCL <= 1.10 computeMeanAndCovarianceMatrix (default), 1 = PCL >= 1.11 shifted form
     int32_t fuse_color;      // EXTENSION: 1 = per-voxel mean colour of the cylinder members (definition in extract())
+    int32_t dense;           // 1 = the reference's storage: one 16-byte Voxel per cell of the (dim+1)^3 box (grid.hpp:108,626);
+                             //     0 = hash map of touched cells (needed for the 10^10-cell configs).  Same results either way.
 };
 
 class Oracle {
@@ -310,8 +313,48 @@ public:
                     dz.push_back(kk);
                 }
         ball_r_f = (float)c.ball_radius;
+        if (c.dense) {  // construct(), grid.hpp:626: (xdim+1)(ydim+1)(zdim+1) voxels of {bool occupied; void* data}
+            dense_n_ = (size_t)(xdim_ + 1) * (size_t)(ydim_ + 1) * (size_t)(zdim_ + 1);
+            dense_ = (Voxel*)calloc(dense_n_, sizeof(Voxel));  // all-zero = {false, nullptr}; pages are touched on first use
+        }
     }
-    ~Oracle() { clear(); }
+    ~Oracle()
+    {
+        clear();
+        free(dense_);
+    }
+    Oracle(const Oracle&) = delete;
+    Oracle& operator=(const Oracle&) = delete;
+
+    // ---- voxel storage: dense array as the reference, or a hash map of touched cells ----
+    Voxel* dense_ = nullptr;
+    size_t dense_n_ = 0;
+    std::vector<uint64_t> dense_live_;  // keys of cells whose Voxel::data was ever set (what the map would hold)
+    size_t dense_index(int x, int y, int z) const { return ((size_t)x * (size_t)(ydim_ + 1) + (size_t)y) * (size_t)(zdim_ + 1) + (size_t)z; }
+    Voxel* find_voxel(int x, int y, int z)  // nullptr when the cell was never touched (sparse mode only)
+    {
+        if (dense_) return &dense_[dense_index(x, y, z)];
+        auto it = voxels_.find(own_key(x, y, z));
+        return it == voxels_.end() ? nullptr : &it->second;
+    }
+    Voxel& get_voxel(int x, int y, int z) { return dense_ ? dense_[dense_index(x, y, z)] : voxels_[own_key(x, y, z)]; }
+    void note_live(int x, int y, int z)  // call when a cell's data pointer goes from null to set
+    {
+        if (dense_) dense_live_.push_back(own_key(x, y, z));
+    }
+    template <class F>
+    void for_each_voxel(F f) const  // f(key, const Voxel&) over every cell that has (or had) a record
+    {
+        if (dense_) {
+            for (uint64_t k : dense_live_) {
+                int x, y, z;
+                own_coords(k, x, y, z);
+                f(k, dense_[dense_index(x, y, z)]);
+            }
+        } else {
+            for (auto& kv : voxels_) f(kv.first, kv.second);
+        }
+    }
 
     Config cfg;
     double xmin_, xmax_, ymin_, ymax_, zmin_, zmax_;
@@ -374,6 +417,10 @@ public:
 
     Voxel lookup(int x, int y, int z) const
     {
+        if (dense_) {
+            if (x < 0 || y < 0 || z < 0 || x > xdim_ || y > ydim_ || z > zdim_) return Voxel();
+            return dense_[dense_index(x, y, z)];
+        }
         auto it = voxels_.find(own_key(x, y, z));
         if (it == voxels_.end()) return Voxel();
         return it->second;
@@ -418,7 +465,7 @@ public:
             if (x == INT_MIN || y == INT_MIN || z == INT_MIN) continue;  // NaN coordinate: reference would crash
             n_inserted++;
             const unsigned long long hash = set_key(x, y, z);
-            Voxel& voxel = voxels_[own_key(x, y, z)];
+            Voxel& voxel = get_voxel(x, y, z);
             const V3 ptv = point;
             if (voxel.occupied) {
                 VoxelInfo* data = voxel.data;
@@ -438,6 +485,7 @@ public:
                     data->buffer.push_back(ptv);
                     if (color) data->buffer_rgb.push_back(rgb[p]);
                     voxel.data = data;
+                    note_live(x, y, z);
                 } else {
                     VoxelInfo* data = voxel.data;  // block attached by a clean pass, grid.hpp:234-241
                     if (cfg.reserve > 0) data->buffer.reserve((size_t)cfg.reserve);
@@ -452,7 +500,7 @@ public:
             for (int i = 0; i < d_size; i++) {
                 int xx, yy, zz;
                 own_coords(data->dependants[i], xx, yy, zz);
-                VoxelInfo* dep = voxels_.find(own_key(xx, yy, zz))->second.data;
+                VoxelInfo* dep = find_voxel(xx, yy, zz)->data;
                 V3 dep_centre = voxel_center(xx, yy, zz);
                 V3 proj = project_point_to_vector(ptv, dep_centre, dep->normal, ball_r_f);
                 double distance_to_normal = (double)norm3(sub3(ptv, proj));
@@ -519,9 +567,9 @@ public:
         for (size_t ki = 0; ki < keys.size(); ki++) {
             int x, y, z;
             own_coords(keys[ki], x, y, z);
-            auto vit = voxels_.find(keys[ki]);
-            if (vit == voxels_.end() || !vit->second.occupied) continue;
-            VoxelInfo* data = vit->second.data;
+            Voxel* vit = find_voxel(x, y, z);
+            if (vit == nullptr || !vit->occupied) continue;
+            VoxelInfo* data = vit->data;
             int total = 0;
             available.clear();
             const int nd = (int)dx.size();
@@ -559,7 +607,7 @@ public:
                     voxel_coords(nb, xx, yy, zz);
                     if (xx == INT_MIN || yy == INT_MIN || zz == INT_MIN) continue;
                     if (!valid_coord(xx, yy, zz)) continue;
-                    Voxel& nv = voxels_[own_key(xx, yy, zz)];
+                    Voxel& nv = get_voxel(xx, yy, zz);
                     if (nv.occupied) {
                         VoxelInfo* nd_ = nv.data;
                         nd_->dependants.push_back(hash);
@@ -576,6 +624,7 @@ public:
                         }
                     } else {
                         // grid.hpp:443-449: overwrites any previous dependants-only block (leak in the reference)
+                        if (nv.data == nullptr) note_live(xx, yy, zz);
                         delete nv.data;
                         VoxelInfo* fresh = new VoxelInfo();
                         fresh->dependants.push_back(hash);
@@ -590,19 +639,19 @@ public:
     void extract(std::vector<Row>& rows) const
     {
         std::vector<uint64_t> keys;
-        for (auto& kv : voxels_) {
-            if (!kv.second.occupied || !kv.second.data->normal_found) continue;
+        for_each_voxel([&](uint64_t key, const Voxel& v) {
+            if (!v.occupied || !v.data->normal_found) return;
             int x, y, z;
-            own_coords(kv.first, x, y, z);
-            if (!valid_coord(x, y, z)) continue;
-            keys.push_back(kv.first);
-        }
+            own_coords(key, x, y, z);
+            if (!valid_coord(x, y, z)) return;
+            keys.push_back(key);
+        });
         std::sort(keys.begin(), keys.end());
         rows.resize(keys.size());
         for (size_t i = 0; i < keys.size(); i++) {
-            const VoxelInfo* d = voxels_.find(keys[i])->second.data;
             Row& r = rows[i];
             own_coords(keys[i], r.ix, r.iy, r.iz);
+            const VoxelInfo* d = const_cast<Oracle*>(this)->find_voxel(r.ix, r.iy, r.iz)->data;
             r.count = (uint32_t)d->count;
             r.x = d->centroid.x;
             r.y = d->centroid.y;
@@ -890,7 +939,15 @@ public:
                 shards_[sh].map.clear();
             }
         }
-        for (auto& kv : voxels_) delete kv.second.data;
+        for_each_voxel([&](uint64_t, const Voxel& v) { delete v.data; });
+        if (dense_) {
+            for (uint64_t k : dense_live_) {
+                int x, y, z;
+                own_coords(k, x, y, z);
+                dense_[dense_index(x, y, z)] = Voxel();
+            }
+            dense_live_.clear();
+        }
         voxels_.clear();
         unprocessed_.clear();
         state_changed = true;  // grid.hpp:169
@@ -918,6 +975,7 @@ void horacle_capture(void* h, const void* base, uint64_t n, uint32_t point_step,
 {
     ((Oracle*)h)->capture((const uint8_t*)base, n, point_step, off_x, off_y, off_z, pose);
 }
+int32_t horacle_is_dense(void* h) { return ((Oracle*)h)->dense_ != nullptr ? 1 : 0; }
 void horacle_capture_rgb(void* h, const void* base, uint64_t n, uint32_t point_step, uint32_t off_x, uint32_t off_y,
                          uint32_t off_z, uint32_t off_rgb, const double* pose)
 {
@@ -976,13 +1034,13 @@ void horacle_counters(void* h, uint64_t out[6])
     out[1] = o->n_zclip_pass;
     out[2] = o->n_inserted;
     uint64_t occ = 0, nf = 0, buffered = 0;
-    for (auto& kv : o->voxels_) {
-        if (kv.second.occupied) occ++;
-        if (kv.second.data) {
-            if (kv.second.data->normal_found) nf++;
-            buffered += kv.second.data->buffer.size();
+    o->for_each_voxel([&](uint64_t, const Voxel& v) {
+        if (v.occupied) occ++;
+        if (v.data) {
+            if (v.data->normal_found) nf++;
+            buffered += v.data->buffer.size();
         }
-    }
+    });
     out[3] = occ;
     out[4] = nf;
     out[5] = buffered;
@@ -992,8 +1050,9 @@ uint64_t horacle_occupied(void* h, int32_t* xyz, uint64_t cap)
 {
     Oracle* o = (Oracle*)h;
     std::vector<uint64_t> keys;
-    for (auto& kv : o->voxels_)
-        if (kv.second.occupied) keys.push_back(kv.first);
+    o->for_each_voxel([&](uint64_t key, const Voxel& v) {
+        if (v.occupied) keys.push_back(key);
+    });
     std::sort(keys.begin(), keys.end());
     if (xyz) {
         uint64_t n = std::min<uint64_t>(cap, keys.size());

@@ -28,6 +28,7 @@ class Config(C.Structure):
         ("reserve", C.c_int32),
         ("pcl_shifted_cov", C.c_int32),
         ("fuse_color", C.c_int32),
+        ("dense", C.c_int32),
     ]
 
 
@@ -65,6 +66,8 @@ def lib():
                                       C.c_uint32, C.c_void_p]
         L.horacle_capture_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.c_void_p]
+        L.horacle_is_dense.argtypes = [C.c_void_p]
+        L.horacle_is_dense.restype = C.c_int32
         L.horacle_add_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.horacle_clean.argtypes = [C.c_void_p]
         L.horacle_capture_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -107,7 +110,7 @@ def _p(a):
 
 
 def make_config(resolution=0.005, bbox=(-0.8, 1.8, -1.5, 1.5, 0.0, 1.0), k=2, K=3, gate=20, cylinder_radius=0.001,
-                ball_radius=0.015, z_clip=(0.28, 0.6), order_mode=0, reserve=0, pcl_shifted_cov=False, fuse_color=False):
+                ball_radius=0.015, z_clip=(0.28, 0.6), order_mode=0, reserve=0, pcl_shifted_cov=False, fuse_color=False, dense=False):
     """Defaults are the reference's constants (node.cpp:91-93,163,311; grid.hpp:34-36,352; launch:7)."""
     c = Config()
     c.resolution = resolution
@@ -119,6 +122,7 @@ def make_config(resolution=0.005, bbox=(-0.8, 1.8, -1.5, 1.5, 0.0, 1.0), k=2, K=
     c.order_mode, c.reserve = order_mode, reserve
     c.pcl_shifted_cov = 1 if pcl_shifted_cov else 0
     c.fuse_color = 1 if fuse_color else 0  # EXTENSION (not in the reference): mean colour of the cylinder members
+    c.dense = 1 if dense else 0  # the reference's storage: 16 B per cell of the whole box (grid.hpp:626) instead of a hash map
     return c
 
 
@@ -144,6 +148,11 @@ class OracleGrid:
             self.close()
         except Exception:
             pass
+
+    @property
+    def is_dense(self):
+        """True when the dense (dim+1)^3 voxel array of the reference could be allocated (dense=True asked for it)."""
+        return bool(lib().horacle_is_dense(self._h))
 
     @property
     def dims(self):

@@ -32,8 +32,8 @@ def test_bench_prints_one_contract_line():
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
-    assert d["cpu_baseline_all_cores"]["cores"] >= 1
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "dense" in c["sample"]
+    assert d["cpu_baseline_sparse"]["cores"] == 1 and d["cpu_baseline_all_cores"]["cores"] >= 1
     assert d["rows_extracted"] > 0
     # 12 steps of 4 frames, clean every 3 steps: the steady state (dependant updates) is inside the timed region
     assert d["config"]["points_per_step"] == 4 * 640 * 480 and d["config"]["frames"] == 48

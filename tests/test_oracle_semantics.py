@@ -204,3 +204,21 @@ def test_all_cores_timing_variant_computes_the_same_map(oracle_mod, synth_mod):
     scenes.compare_rows(ra, rb)
     gb.clear()
     assert gb.normals_mt() == 0
+
+
+def test_dense_storage_and_reserve_give_the_same_rows(oracle_mod, synth_mod):
+    """The reference's storage -- one 16-byte Voxel per cell of the (dim+1)^3 box and buffer.reserve(1000) per new voxel
+    (grid.hpp:626,228) -- against the hash map of touched cells the oracle uses by default: same rows, same occupancy.
+    (bench.py times the dense + reserve variant as the faithful CPU baseline where the host has the memory.)"""
+    import scenes
+    bbox = (-0.3, 0.3, -0.3, 0.3, 0.2, 0.7)  # 600 x 600 x 500 cells at 1 mm: 2.9 GB of virtual Voxel array, touched sparsely
+    sc = scenes.Scene(4, 160, 120, 0.001, bbox=bbox, fx=615.0, clean_every=2)
+    a = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=bbox)
+    b = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=bbox, dense=True, reserve=1000)
+    assert b.is_dense and not a.is_dense
+    ra, rb = scenes.run(a, sc, "capture"), scenes.run(b, sc, "capture")
+    assert len(ra) > 1000 and ra.tobytes() == rb.tobytes()
+    assert np.array_equal(a.occupied(), b.occupied())
+    assert a.counters() == b.counters()
+    b.clear()
+    assert len(b.extract()) == 0 and b.counters()["occupied"] == 0
