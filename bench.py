@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed passes over the K-step stream (median reported)")
     ap.add_argument("--frames-per-call", type=int, default=0, help="frames handed to one hfpf_integrate_device call (0 = one clean epoch)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames timed on the CPU oracle, sparse and all-cores variants (0 = skip all CPU legs)")
-    ap.add_argument("--cpu-sample-faithful", type=int, default=8, help="frames timed on the faithful variant (dense voxel array + reserve(1000): ~3 s per frame)")
+    ap.add_argument("--cpu-sample-faithful", type=int, default=24, help="frames timed on the faithful variant (dense voxel array + reserve(1000); ~0.4 s per frame on the GPU box)")
     ap.add_argument("--write-dir", default=None, help="also time writing test_cloud.pcd (ASCII + binary) and meta.csv there")
     ap.add_argument("--host-path-frames", type=int, default=200, help="frames also pushed through the host-buffer entry point (0 = skip)")
     ap.add_argument("--allow-host-staged", action="store_true", help="rehearsals with several ranks on ONE GPU: fall back to the gloo host-staged transport when RCCL cannot form a communicator")
