@@ -191,7 +191,7 @@ def main():
         if n_dev > 0:
             device = local_rank % n_dev  # rehearsals with more ranks than GPUs share devices
     grid = hfpf.OccupancyGrid(resolution=RES, bbox=BBOX, device=device, max_bricks=400000,
-                              max_log_points=min(max(n_gen, 64) * NPTS, 1 << 31), max_normals=24 << 20,
+                              max_log_points=min(max(n_gen, 64) * NPTS, (1 << 31) - 64), max_normals=24 << 20,
                               max_frames=max(n_gen * max(world, 1) + 16, 4096),
                               frame_width=int(os.environ.get("HFPF_FRAME_WIDTH", W)),  # organised W x H frames: 16x16-pixel tiles
                               max_call_points=call_frames * NPTS)  # per-call bins sized at create, like the other pools

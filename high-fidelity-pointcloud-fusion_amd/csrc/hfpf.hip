@@ -60,6 +60,7 @@ struct FrameSlot {  // host-frame staging (pinned + device)
 };
 
 constexpr int kStageSlots = 8;
+constexpr int kProbeFrames = 8;  // frames of a plan-less batch that go ahead of the rest to measure the per-brick demand
 constexpr int kFrameSlots = 8;  // uploads run ahead of the kernels by up to this many frames
 
 }  // namespace
@@ -91,7 +92,8 @@ struct hfpf_handle {
     // further work (HFPF_ERR_STATE) until hfpf_clear, instead of silently losing candidates on a retry.
     bool poisoned = false;
     std::string poison_msg;
-    bool pend_valid = false; // pend_a holds C_PEND cells that a gate pass examined and left without a normal
+    bool pend_valid = false;
+    uint64_t direct_linked = 0;  // points buffered by k_integrate's direct form (C_BUFFERED) that k_link_log has already chained // pend_a holds C_PEND cells that a gate pass examined and left without a normal
     DevBuf pend_a, pend_b;
     uint64_t clean_passes = 0;
     uint32_t next_frame_id = 0;
@@ -318,10 +320,11 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.nd_mask, 0, (t.max_bricks + 1) * 8 * 2 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.ctr, 0, C_COUNT * 8, s));
     HIPCHK(h, hipMemsetAsync(t.log_ctr, 0, kLogRegions * 16 * 8, s));
-    HIPCHK(h, hipMemsetAsync(t.bin_fill, 0, (t.max_bricks + 2) * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.bin_off, 0, (t.max_bricks + 2) * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.bin_capb, 0, (t.max_bricks + 2) * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.bin_fill, 0, 2 * (t.max_bricks + 2) * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.bin_off, 0, 2 * (t.max_bricks + 2) * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.bin_capb, 0, 2 * (t.max_bricks + 2) * 4, s));
     h->bin_have_hist = false;
+    h->direct_linked = 0;
     h->n_bricks_known = 0;
     if (h->h_ctr) memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));  // host mirror follows the device counters
     h->dirty = false;
@@ -347,7 +350,8 @@ int alloc_tables(hfpf_handle* h)
     if (c.max_frames == 0) c.max_frames = 65536;
     if (c.max_bricks > 8388606ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_bricks must be < 2^23");
     c.max_log_points = std::max<uint64_t>(c.max_log_points, 64 * kLogRegions);
-    if (c.max_log_points > 4294967294ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_log_points must be < 2^32-1");
+    if (c.max_log_points > 0x7FFFFFF0ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_log_points must be < 2^31 (bit 31 of a log link marks an unchained entry)");
+    if (c.max_frames > (1ull << 23)) return fail(h, HFPF_ERR_BAD_CONFIG, "max_frames must be <= 2^23 (a parked point carries its frame id in 23 bits)");
     if (c.max_normals > 4294967294ull) return fail(h, HFPF_ERR_BAD_CONFIG, "max_normals must be < 2^32-1");
     t.max_bricks = c.max_bricks;
     t.max_log = c.max_log_points;
@@ -391,9 +395,9 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(frame_vp, 3 * t.max_frames);
     ALLOC(ctr, C_COUNT);
     ALLOC(log_ctr, kLogRegions * 16);
-    ALLOC(bin_fill, t.max_bricks + 2);
-    ALLOC(bin_off, t.max_bricks + 2);
-    ALLOC(bin_capb, t.max_bricks + 2);
+    ALLOC(bin_fill, 2 * (t.max_bricks + 2));
+    ALLOC(bin_off, 2 * (t.max_bricks + 2));
+    ALLOC(bin_capb, 2 * (t.max_bricks + 2));
     h->binned = (c.flags & HFPF_FLAG_DIRECT_UPDATE) == 0;
 #undef ALLOC
     t.log_region_cap = t.max_log / kLogRegions;
@@ -471,6 +475,16 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     if (std::max(std::max(off_x, off_y), std::max(off_z, off_rgb)) + 4 > point_step)
         return fail(h, HFPF_ERR_BAD_ARG, "integrate: field offset beyond point_step");
     if (n_frames > 65535) return fail(h, HFPF_ERR_BAD_ARG, "integrate: at most 65535 frames per call");
+    if (h->binned && !h->bin_have_hist && n_frames > (uint32_t)kProbeFrames) {
+        // No plan for the per-brick bins yet (first call of a session): a short head of the batch goes through the direct forms
+        // and records the demand; the rest is binned with that demand scaled up.  One extra read-back, once per session.
+        int rc0 = integrate_device_locked(h, dev_base, kProbeFrames, frame_stride, n_points, point_step, off_x, off_y, off_z, off_rgb, poses, frame_ids);
+        if (rc0) return rc0;
+        if ((rc0 = read_counters(h))) return rc0;  // bricks the head allocated
+        return integrate_device_locked(h, (const char*)dev_base + (size_t)kProbeFrames * frame_stride, n_frames - kProbeFrames, frame_stride, n_points,
+                                       point_step, off_x, off_y, off_z, off_rgb, poses + 12 * (size_t)kProbeFrames,
+                                       frame_ids ? frame_ids + kProbeFrames : nullptr);
+    }
     if ((uint64_t)blocks_for(n_points, 256) * n_frames >= 0xFFFFFFFFull) return fail(h, HFPF_ERR_BAD_ARG, "integrate: batch too large (split the call)");
     StageSlot* s = nullptr;
     int rc = acquire_stage(h, n_frames, &s);
@@ -511,11 +525,12 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     const bool color = h->t.color != 0;
     const bool bin = h->binned;
     const uint32_t nb = (uint32_t)h->n_bricks_known;
-    const bool demand_only = h->h_ctr[C_NORMALS] == 0;  // as of the last clean: nothing can have dependants yet
+    // a plan = per-brick bin regions sized from the previous launch's demand; without one nothing is parked (direct forms)
+    const bool have_plan = bin && h->bin_have_hist && nb > 0;
     if (bin) {
         // pool for this launch's parked points (+25 % plan slack, +64 per brick)
         const uint64_t pts = (uint64_t)n_points * n_frames;
-        const uint64_t pool = pts + pts / 3 + 64ull * (nb + 1);
+        const uint64_t pool = 2 * (pts + pts / 3) + 128ull * (nb + 1);  // two regions per brick, each sized for the whole brick
         if (pool > 0xFFFFFFFFull) return fail(h, HFPF_ERR_BAD_ARG, "integrate: batch too large for the binned update (split the call)");
         if (h->bin_pool < pool) {
             int rc2 = scratch(h, h->bin_pt_buf, pool * sizeof(float4));
@@ -524,20 +539,21 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
             h->bin_pool = pool;
         }
         h->t.bin_pt = (float4*)h->bin_pt_buf.p;
-        h->t.bin_demand_only = demand_only ? 1u : 0u;
         h->t.bin_rgb = (uint32_t*)h->bin_rgb_buf.p;
-        if (h->bin_have_hist && nb > 0 && !demand_only) {
+        if (have_plan) {
             const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points));
-            hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, h->stream, h->t, nb, scale);
+            const uint32_t n_regions = 2u * (nb + 1u);  // two per brick: cells with / without a normal
+            hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(n_regions, 256)), dim3(256), 0, h->stream, h->t, n_regions, scale);
             size_t bytes = 0;
-            HIPCHK(h, rocprim::exclusive_scan(nullptr, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), h->stream));
+            HIPCHK(h, rocprim::exclusive_scan(nullptr, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_regions, rocprim::plus<uint32_t>(), h->stream));
             int rc2 = scratch(h, h->sort_tmp, bytes);
             if (rc2) return rc2;
             bytes = h->sort_tmp.bytes;
-            HIPCHK(h, rocprim::exclusive_scan(h->sort_tmp.p, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), h->stream));
-            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, h->stream, h->t, nb, h->bin_pool);
-        } else {
-            HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, (h->t.max_bricks + 2) * 4, h->stream));  // no plan yet: every lane goes direct, demand is recorded
+            HIPCHK(h, rocprim::exclusive_scan(h->sort_tmp.p, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_regions, rocprim::plus<uint32_t>(), h->stream));
+            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(n_regions, 256)), dim3(256), 0, h->stream, h->t, n_regions, h->bin_pool);
+        } else {  // no plan yet: no region exists, every lane takes the direct forms, the demand is recorded
+            HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->t.bin_capb, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
         }
     }
     const uint32_t log_rot = (uint32_t)((h->launch_seq++ * 17u) & (kLogRegions - 1));
@@ -554,9 +570,13 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, true);
         else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, true);
         else HFPF_LAUNCH_INTEGRATE(false, true, true);
-        if (nb > 0 && h->bin_have_hist && !demand_only) {
-            if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
-            else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
+        if (have_plan) {
+            if (h->h_ctr[C_NORMALS] > 0) {  // as of the last clean: without a normal record no cell has dependants
+                if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
+                else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
+            }
+            if (color) hipLaunchKernelGGL(k_buffer<true>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
+            else hipLaunchKernelGGL(k_buffer<false>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
         }
         h->bin_have_hist = true;
         h->bin_prev_points = (double)n_points * n_frames;
@@ -785,10 +805,12 @@ int clean_locked(hfpf_handle* h)
             max_new = std::max(max_new, n_r - h->n_linked[r]);
             h->n_linked[r] = n_r;
         }
-        if (max_new) {
+        // entries appended by k_buffer arrive chained; only k_integrate's direct form leaves marked entries behind
+        if (max_new && h->h_ctr[C_BUFFERED] != h->direct_linked) {
             hipLaunchKernelGGL(k_link_log, dim3(blocks_for(max_new, 256), kLogRegions), dim3(256), 0, s, t, lr);
             HIPCHK(h, hipGetLastError());
         }
+        h->direct_linked = h->h_ctr[C_BUFFERED];
     }
     if (n_occ == 0) return HFPF_OK;
 
@@ -961,7 +983,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
             return bail(rc);
         if (h->cfg.max_call_points && h->binned) {
             const uint64_t pts = h->cfg.max_call_points;
-            const uint64_t pool = std::min<uint64_t>(pts + pts / 3 + 64ull * (h->cfg.max_bricks + 1), 0xFFFFFFFFull);
+            const uint64_t pool = std::min<uint64_t>(2 * (pts + pts / 3) + 128ull * (h->cfg.max_bricks + 1), 0xFFFFFFFFull);
             if ((rc = scratch(h, h->bin_pt_buf, pool * sizeof(float4)))) return bail(rc);
             if (h->t.color && (rc = scratch(h, h->bin_rgb_buf, pool * 4))) return bail(rc);
             h->bin_pool = pool;

@@ -41,6 +41,7 @@ struct FrameLayout {
 #define HFPF_REPLAY_B 3  // registrants per chain walk held in registers by k_replay
 #endif
 constexpr int kLogRegions = 64;
+constexpr uint32_t kLogUnlinked = 0x80000000u;  // log entry .w = slot | this bit until the entry is chained (then: index of the next entry)
 #ifndef HFPF_REG_TILES
 #define HFPF_REG_TILES 8  // 256-voxel tiles one workgroup of k_register takes per list reservation
 #endif
@@ -251,37 +252,24 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             }
         }
 
-        // buffer while the voxel has no normal (grid.hpp:210-211,230,239); the viewpoint latch (smallest frame
-        // id that touched the cell, grid.hpp:229,238) is only ever read before the normal exists.
-        const bool buf = act && !has_n;
-        if (buf && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
-        const unsigned long long li = wave_reserve(log_ctr, buf);
-        if (buf) {
-            if (li < t.log_region_cap) {
-                const uint64_t e = log_base + li + 1;
-                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));  // .w: slot until linked, then `next`
-                if (COLOR) t.log_rgb[e] = rgb;
-            } else {
-                atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
-            }
-        }
-        c_buf += buf;
-
-        // dependant updates (grid.hpp:244-277)
-        bool direct = act && has_d;  // still to be handled by this kernel
+        // What is left to do with the point: buffer it while its voxel has no normal (grid.hpp:210-211,230,239) and update the
+        // voxel's dependants (grid.hpp:244-277).  Binned form (BIN = true, default): both are handed to the per-brick kernels --
+        // the point is parked in its brick's bin, k_update accumulates the brick's records in LDS and flushes each once per
+        // launch, k_buffer appends the brick's buffered points to the log as one run and links them into their cells' chains
+        // with LDS exchanges.  One reservation per distinct brick per wave (ballot grouping); a lane whose brick region is
+        // full or unplanned stays `todo` and takes the direct forms below, so correctness never depends on the plan.
+        bool todo = act && (has_d || !has_n);
         if (BIN) {
-            // Two-pass form: park the point in its brick's bin; k_update accumulates every brick's records in LDS and
-            // flushes each record once per launch instead of once per (point, dependant) pair.  One reservation per
-            // distinct brick per wave (ballot grouping); a lane whose brick region is full (or unplanned) stays `direct`
-            // and takes the loop below, so correctness never depends on the plan.
-            const bool want_bin = direct || (act && t.bin_demand_only);
-            // phase 1 (registers only): group the lanes by brick -> leader lane, rank in group, group size
+            const bool want_bin = todo;
+            // phase 1 (registers only): group the lanes by bin region (brick x {cell has a normal, cell has none}) -> leader
+            // lane, rank in group, group size
+            const uint32_t rg = 2u * b + (has_n ? 0u : 1u);
             uint32_t grp_leader = lane, grp_rank = 0, grp_size = 0;
             unsigned long long m = __ballot(want_bin);
             while (m) {
                 const int leader = __ffsll((long long)m) - 1;
-                const uint32_t lb = __shfl(b, leader);
-                const bool same = want_bin && b == lb;
+                const uint32_t lb = __shfl(rg, leader);
+                const bool same = want_bin && rg == lb;
                 const unsigned long long sm = __ballot(same);
                 if (same) {
                     grp_leader = (uint32_t)leader;
@@ -290,27 +278,48 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
                 }
                 m &= ~sm;
             }
-            // phase 2: every group leader reserves for its group in ONE wave-instruction (one memory round trip per tile)
+            // phase 2: every group leader reserves for its group in ONE wave-instruction (one memory round trip per tile);
+            // the counter also records the demand the next launch's plan is made from
             uint32_t base = 0, cap = 0, roff = 0;
             if (want_bin && grp_leader == lane) {
-                base = atomicAdd(&t.bin_fill[b], grp_size);
-                cap = t.bin_capb[b];
-                roff = t.bin_off[b];
+                base = atomicAdd(&t.bin_fill[rg], grp_size);
+                cap = t.bin_capb[rg];
+                roff = t.bin_off[rg];
             }
             base = __shfl(base, (int)grp_leader);
             cap = __shfl(cap, (int)grp_leader);
             roff = __shfl(roff, (int)grp_leader);
-            if (direct) {
+            if (todo) {
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
                     const uint64_t e = (uint64_t)roff + pos;
-                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(lcell));  // the point + its cell inside the brick; read back once by k_update
+                    // the point + its cell inside the brick + its frame id (viewpoint latch); read back by k_update / k_buffer
+                    t.bin_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(lcell | (fid << 9)));
                     if (COLOR) t.bin_rgb[e] = rgb;
-                    direct = false;  // handled by k_update
+                    todo = false;
                 }
             }
         }
-        if (__ballot(direct) == 0) continue;  // wave-uniform; the common case of the binned form
+        if (__ballot(todo) == 0) continue;  // wave-uniform; the common case of the binned form
+
+        // direct buffering; the viewpoint latch (smallest frame id that touched the cell, grid.hpp:229,238) is only ever
+        // read before the normal exists
+        const bool buf = todo && !has_n;
+        if (buf && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
+        const unsigned long long li = wave_reserve(log_ctr, buf);
+        if (buf) {
+            if (li < t.log_region_cap) {
+                const uint64_t e = log_base + li + 1;
+                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(slot | kLogUnlinked));  // .w: marked slot until k_link_log chains it
+                if (COLOR) t.log_rgb[e] = rgb;
+            } else {
+                atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
+            }
+        }
+        c_buf += buf;
+
+        // direct dependant updates
+        const bool direct = todo && has_d;
         uint32_t cnt = 0;
         uint64_t off = 0;
         if (direct) {
@@ -391,12 +400,15 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
     __shared__ unsigned int blk_ctr[2];
     const uint32_t b = blockIdx.x + 1;
     if (b > n_bricks) return;
-    const uint32_t fill = min(t.bin_fill[b], t.bin_capb[b]);
+    // the brick's two bin regions (cells with / without a normal) as one index space [0, fill)
+    const uint32_t fill_a = min(t.bin_fill[2 * b], t.bin_capb[2 * b]), fill_b = min(t.bin_fill[2 * b + 1], t.bin_capb[2 * b + 1]);
+    const uint32_t fill = fill_a + fill_b;
     if (fill == 0) return;  // block-uniform
     const uint32_t tid = threadIdx.x;
-    const uint64_t first = t.bin_off[b];
+    const uint64_t first_a = t.bin_off[2 * b], first_b = t.bin_off[2 * b + 1];
+    auto entry = [&](uint32_t i) -> uint64_t { return i < fill_a ? first_a + i : first_b + (i - fill_a); };
     float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid / kUpdLanes < fill) pe = t.bin_pt[first + tid / kUpdLanes];  // in flight while the tables are set up
+    if (tid / kUpdLanes < fill) pe = t.bin_pt[entry(tid / kUpdLanes)];  // in flight while the tables are set up
     {
         const ulonglong2 inf = *reinterpret_cast<const ulonglong2*>(&t.info[(uint64_t)b * kBrickCells + 2u * tid]);
         for (uint32_t i = tid; i < (uint32_t)kUpdSlots; i += 256) keys[i] = 0;
@@ -414,8 +426,8 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
     const uint32_t sub = tid % kUpdLanes;
     for (uint32_t i = tid / kUpdLanes; i < fill; i += 256 / kUpdLanes) {
         const float4 cur = pe;
-        const uint32_t rgb = COLOR ? t.bin_rgb[first + i] : 0u;
-        if (i + 256 / kUpdLanes < fill) pe = t.bin_pt[first + i + 256 / kUpdLanes];  // next point: in flight during this one's pairs
+        const uint32_t rgb = COLOR ? t.bin_rgb[entry(i)] : 0u;
+        if (i + 256 / kUpdLanes < fill) pe = t.bin_pt[entry(i + 256 / kUpdLanes)];  // next point: in flight during this one's pairs
         const F3 p = F3{cur.x, cur.y, cur.z};
         const uint64_t info = s_info[__float_as_uint(cur.w) & (kBrickCells - 1)];
         const uint32_t cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
@@ -497,32 +509,101 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
         atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
 }
 
-// Plan the brick regions of the next launch from the demand of the previous one: cap = demand * scale * 1.25 + 64.
-__global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_bricks, const float scale)
+// ------------------------------------------------------------------------------------------------
+// K2b: the brick's parked points whose cell has no normal yet (its second bin region) are appended to the point log as ONE
+// run (one reservation per brick and launch) and chained into their cells' four chains.  A long run (the first epoch:
+// everything is buffered) chains with LDS exchanges, the chain heads travelling as one coalesced 8 KB read and write per
+// brick; a short run (steady state: a few edge cells) exchanges straight on the heads in global memory.  Replaces one
+// returning device atomic per buffered point in a separate pass over the log (k_link_log's atomicExch, ~1.2 ms for the
+// first epoch's 39 M entries) and keeps a cell's entries of one launch within a few KB of each other for the replay's
+// chain walks.
+constexpr uint32_t kChains = 4;       // interleaved chains per cell: k_replay walks them with 4 lanes in parallel
+constexpr uint32_t kBufLdsMin = 256;  // runs at least this long chain in LDS
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_buffer(const GridParams g, const Tables t, const uint32_t n_bricks)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_head[kBrickCells * kChains];  // chain heads of the brick's cells
+    __shared__ uint32_t s_minfid[kBrickCells];          // smallest frame id that buffered into the cell in this launch
+    __shared__ unsigned long long s_base;
+    const uint32_t b = blockIdx.x + 1;
     if (b > n_bricks) return;
+    const uint32_t n_buf = min(t.bin_fill[2 * b + 1], t.bin_capb[2 * b + 1]);
+    if (n_buf == 0) return;  // block-uniform
+    const uint32_t tid = threadIdx.x;
+    const uint64_t first = t.bin_off[2 * b + 1];
+    const uint32_t region = b & (kLogRegions - 1);
+    const bool in_lds = n_buf >= kBufLdsMin;  // block-uniform
+    if (tid == 0) s_base = atomicAdd(&t.log_ctr[region * 16], (unsigned long long)n_buf);
+    if (in_lds) {
+        for (uint32_t i = tid; i < (uint32_t)(kBrickCells * kChains); i += 256) s_head[i] = t.buf_head[(uint64_t)b * kBrickCells * kChains + i];
+        for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += 256) s_minfid[i] = kNoFrame;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    const uint64_t log_base = (uint64_t)region * t.log_region_cap;
+    bool overflow = false;
+    for (uint32_t i = tid; i < n_buf; i += 256) {
+        const unsigned long long k = base + i;
+        if (k >= t.log_region_cap) {
+            overflow = true;
+            continue;
+        }
+        const float4 pe = t.bin_pt[first + i];
+        const uint32_t e = (uint32_t)(log_base + k + 1);
+        const uint32_t w = __float_as_uint(pe.w), lcell = w & (kBrickCells - 1), fid = w >> 9;
+        uint32_t prev;  // entry e joins chain e mod 4 of its cell
+        if (in_lds) {
+            prev = atomicExch(&s_head[lcell * kChains + (e & (kChains - 1))], e);
+            atomicMin(&s_minfid[lcell], fid);
+        } else {
+            const uint64_t slot = (uint64_t)b * kBrickCells + lcell;
+            prev = atomicExch(&t.buf_head[slot * kChains + (e & (kChains - 1))], e);
+            if (fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);  // viewpoint latch, grid.hpp:229,238
+        }
+        t.log_pt[e] = make_float4(pe.x, pe.y, pe.z, __uint_as_float(prev));
+        if (COLOR) t.log_rgb[e] = t.bin_rgb[first + i];
+    }
+    if (overflow) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
+    if (!in_lds) return;
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)(kBrickCells * kChains); i += 256) t.buf_head[(uint64_t)b * kBrickCells * kChains + i] = s_head[i];
+    for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += 256) {  // viewpoint latch: smallest frame id that touched the cell
+        const uint32_t mf = s_minfid[i];
+        if (mf != kNoFrame) {
+            uint32_t* ff = &t.first_frame[(uint64_t)b * kBrickCells + i];
+            if (mf < *ff) atomicMin(ff, mf);
+        }
+    }
+}
+
+// Plan the bin regions of the next launch from the demand of the previous one: cap = demand * scale * 1.25 + 64, where the
+// demand is the BRICK's (both regions): a clean pass between two launches moves cells from "no normal" to "normal", so either
+// region must be able to take all of the brick's points.  n_regions = 2 * (bricks + 1); regions 0 and 1 belong to the null
+// brick and stay empty.
+__global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_regions, const float scale)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
     uint32_t cap = 0;
-    if (b >= 1) {
-        const uint32_t demand = t.bin_fill[b];
+    if (r >= 2) {
+        const uint32_t demand = t.bin_fill[r & ~1u] + t.bin_fill[r | 1u];
         if (demand) cap = (uint32_t)((float)demand * scale * 1.25f) + 64u;
     }
-    t.bin_capb[b] = cap;
+    t.bin_capb[r] = cap;
 }
 
 // After the exclusive scan of the capacities: regions that do not fit the pool are switched off.
-__global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_t n_bricks, const uint64_t pool)
+__global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_t n_regions, const uint64_t pool)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_bricks) return;
-    if ((uint64_t)t.bin_off[b] + t.bin_capb[b] > pool) t.bin_capb[b] = 0;
-    t.bin_fill[b] = 0;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    if ((uint64_t)t.bin_off[r] + t.bin_capb[r] > pool) t.bin_capb[r] = 0;
+    t.bin_fill[r] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Link the log entries appended since the last clean into their cells' chains.  grid.y = log region;
 // [first[r], last[r]] are 1-based global entry indices (empty when first > last).
-constexpr uint32_t kChains = 4;  // interleaved chains per cell: k_replay walks them with 4 lanes in parallel
 struct LinkRanges {
     uint32_t first[kLogRegions];
     uint32_t last[kLogRegions];
@@ -533,7 +614,9 @@ __global__ __launch_bounds__(256) void k_link_log(const Tables t, const LinkRang
     const uint64_t e = (uint64_t)lr.first[r] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e > lr.last[r]) return;
     uint32_t* w = reinterpret_cast<uint32_t*>(&t.log_pt[e]) + 3;
-    const uint32_t slot = *w;
+    const uint32_t v = *w;
+    if (!(v & kLogUnlinked)) return;  // appended and chained by k_buffer
+    const uint32_t slot = v & ~kLogUnlinked;
     *w = atomicExch(&t.buf_head[(uint64_t)slot * kChains + (e & (kChains - 1))], (uint32_t)e);  // entry e joins chain e mod 4 of its cell
 }
 

@@ -125,11 +125,11 @@ struct Tables {
     // brick bins of the two-pass dependant update (kernels.hpp, k_integrate<BIN> + k_update)
     float4* bin_pt;       // (x, y, z, bits of the cell's index inside the brick) of points parked for k_update, grouped per brick
     uint32_t* bin_rgb;    // their colour (HFPF_FLAG_FUSE_COLOR only)
-    uint32_t* bin_fill;   // per brick: entries requested in the running launch (may exceed the region)
-    uint32_t* bin_off;    // per brick: first entry of its region
-    uint32_t* bin_capb;   // per brick: entries its region can hold (0 = not planned: direct atomics)
-    uint32_t bin_demand_only;  // 1 while no voxel has a normal yet: count every in-bbox point per brick so the first
-                               // launch with dependants already has a plan; nothing is parked
+    // Two regions per brick, index 2*brick + kind: kind 0 = points whose cell has a normal (dependant updates only),
+    // kind 1 = points whose cell has none yet (to be buffered by k_buffer, and updated like the others by k_update)
+    uint32_t* bin_fill;   // per region: entries requested in the running launch (may exceed the region)
+    uint32_t* bin_off;    // per region: first entry
+    uint32_t* bin_capb;   // per region: entries it can hold (0 = not planned: direct forms in k_integrate)
     unsigned long long* log_ctr;  // kLogRegions append counters, one per 128-byte line (index r*16)
     uint64_t log_region_cap;      // entries per log region
     uint64_t max_bricks, max_log, max_occ, max_normals, max_reg, max_dep, max_frames;
