@@ -622,32 +622,66 @@ __global__ __launch_bounds__(256) void k_link_log(const Tables t, const LinkRang
 
 // 125-bit occupancy stencil around (x,y,z): bit d = ((dx+2)*5 + (dy+2))*5 + (dz+2), the setK table order
 // (grid.hpp:138-149); only cells with validCoord (grid.hpp:337) can be set.
+// The window [c-2, c+2] spans at most two bricks per axis.  All directory entries (<= 8) are read first, then all plane
+// masks (<= 20 u64), each batch independent loads, and the 5-bit z-runs are cut out with shifts: two memory round trips
+// per call instead of one per (plane, brick), no data-dependent branches.
 __device__ inline void neighbourhood(const GridParams& g, const Tables& t, int32_t x, int32_t y, int32_t z, uint64_t& lo, uint64_t& hi)
 {
     lo = 0;
     hi = 0;
-    const int32_t y0 = max(y - 2, 0), y1 = min(y + 2, g.dim[1] - 1);
-    const int32_t z0 = max(z - 2, 0), z1 = min(z + 2, g.dim[2] - 1);
-    if (y0 > y1 || z0 > z1) return;
-    for (int a = -2; a <= 2; a++) {
-        const int32_t xx = x + a;
-        if (xx < 0 || xx >= g.dim[0]) continue;
-        for (int32_t by = y0 >> 3; by <= (y1 >> 3); by++)
-            for (int32_t bz = z0 >> 3; bz <= (z1 >> 3); bz++) {
-                const uint32_t b = t.dir[((uint32_t)(xx >> 3) * (uint32_t)g.bdim[1] + (uint32_t)by) * (uint32_t)g.bdim[2] + (uint32_t)bz];
-                if (b == 0 || b == kLock) continue;
-                const uint64_t m = t.occ_mask[(uint64_t)b * 8 + (xx & 7)];
-                if (m == 0) continue;
-                const int32_t ya = max(y0, by * 8), yb = min(y1, by * 8 + 7);
-                const int32_t za = max(z0, bz * 8), zb = min(z1, bz * 8 + 7);
-                for (int32_t yy = ya; yy <= yb; yy++)
-                    for (int32_t zz = za; zz <= zb; zz++)
-                        if ((m >> (((yy & 7) << 3) | (zz & 7))) & 1ull) {
-                            const int d = ((a + 2) * 5 + (yy - y + 2)) * 5 + (zz - z + 2);
-                            if (d < 64) lo |= 1ull << d;
-                            else hi |= 1ull << (d - 64);
-                        }
+    const int32_t bx0 = (x - 2) >> 3, by0 = (y - 2) >> 3, bz0 = (z - 2) >> 3;  // arithmetic shifts: -1 below the grid
+    const bool two_x = ((x + 2) >> 3) != bx0, two_y = ((y + 2) >> 3) != by0, two_z = ((z + 2) >> 3) != bz0;
+    uint32_t bid[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int i = q >> 2, j = (q >> 1) & 1, k = q & 1;
+        const int32_t bx = bx0 + i, by = by0 + j, bz = bz0 + k;
+        const bool need = (i == 0 || two_x) && (j == 0 || two_y) && (k == 0 || two_z) && bx >= 0 && by >= 0 && bz >= 0 && bx < g.bdim[0] &&
+                          by < g.bdim[1] && bz < g.bdim[2];
+        uint32_t v = 0;
+        if (need) v = t.dir[((uint32_t)bx * (uint32_t)g.bdim[1] + (uint32_t)by) * (uint32_t)g.bdim[2] + (uint32_t)bz];
+        bid[q] = v == kLock ? 0u : v;
+    }
+    // plane masks of the 5 x-planes in the (up to) 2 x 2 bricks of the y/z window
+    uint64_t pm[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+        const int32_t xx = x + a - 2;
+        const bool vx = xx >= 0 && xx < g.dim[0];
+        const bool hi_x = (xx >> 3) != bx0;
+#pragma unroll
+        for (int jk = 0; jk < 4; jk++) {
+            const uint32_t b = hi_x ? bid[4 + jk] : bid[jk];
+            uint64_t m = 0;
+            if (vx && b) m = t.occ_mask[(uint64_t)b * 8 + ((uint32_t)xx & 7u)];
+            pm[a][jk] = m;
+        }
+    }
+    // z clipping: which of the 5 dz positions are valid cells
+    uint32_t zclip = 0;
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        if (z + c - 2 >= 0 && z + c - 2 < g.dim[2]) zclip |= 1u << c;
+    const uint32_t zsh = (uint32_t)((z - 2) - bz0 * 8);  // 0..7: first z of the window inside the 16-wide line of the two z-bricks
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+#pragma unroll
+        for (int dy = 0; dy < 5; dy++) {
+            const int32_t yy = y + dy - 2;
+            const bool vy = yy >= 0 && yy < g.dim[1];
+            const bool hi_y = (yy >> 3) != by0;
+            const uint32_t sh = ((uint32_t)yy & 7u) * 8u;
+            const uint64_t m0 = hi_y ? pm[a][2] : pm[a][0], m1 = hi_y ? pm[a][3] : pm[a][1];
+            const uint32_t line = (uint32_t)((m0 >> sh) & 0xFFull) | ((uint32_t)((m1 >> sh) & 0xFFull) << 8);
+            uint64_t f = vy ? (uint64_t)((line >> zsh) & 31u & zclip) : 0ull;
+            const int d0 = (a * 5 + dy) * 5;
+            if (d0 < 64) {
+                lo |= f << d0;
+                if (d0 + 5 > 64) hi |= f >> (64 - d0);
+            } else {
+                hi |= f << (d0 - 64);
             }
+        }
     }
 }
 
