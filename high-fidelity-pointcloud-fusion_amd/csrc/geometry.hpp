@@ -37,6 +37,9 @@ struct GridParams {
     // fixed-point scales (powers of two) of the order-free statistic sums, see stats.hpp
     float fs_scale, fss_scale, fd_scale, fdd_scale;
     float d2_max;  // largest f32 u with (double)sqrtf(u) < cyl_r: membership as one compare on the squared distance
+    // cell key = x << key_sx | y << key_sy | z with just enough bits per axis for 0..dim: ascending keys = the reference's
+    // lexicographic (x,y,z) scan order, and the radix sorts run over key_bits bits (30 at 999^3) instead of 64
+    uint32_t key_sy, key_sx, key_bits;
 };
 
 HFPF_HD float sum3(float a, float b, float c) { return a + (b + c); }  // Eigen fixed-size-3 redux: c0 + (c1 + c2)

@@ -272,6 +272,16 @@ int setup_params(hfpf_handle* h)
         g.dim[a] = (int32_t)d;
         g.bdim[a] = (g.dim[a] + 1 + 7) / 8;  // storage is dim+1 cells, grid.hpp:626
     }
+    {
+        auto bits_for = [](int32_t dim) {  // bits that hold 0..dim (storage is dim+1 cells per axis, grid.hpp:626)
+            uint32_t b = 1;
+            while ((1ll << b) <= (long long)dim) b++;
+            return b;
+        };
+        g.key_sy = bits_for(g.dim[2]);
+        g.key_sx = g.key_sy + bits_for(g.dim[1]);
+        g.key_bits = g.key_sx + bits_for(g.dim[0]);
+    }
     g.zclip_min = c.z_clip_min;
     g.zclip_max = c.z_clip_max;
     g.cyl_r = c.cylinder_radius;
@@ -404,14 +414,17 @@ int alloc_tables(hfpf_handle* h)
     return reset_state(h);
 }
 
+// Cell keys: only the low GridParams::key_bits bits are significant (an all-ones sentinel still sorts behind every valid key:
+// a valid cell has x < dim <= 2^bits_x - 1, so its key is never all ones).
 int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n)
 {
+    const unsigned kb = h->g.key_bits;
     size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, 64, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
     bytes = h->sort_tmp.bytes;
-    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, 64, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, kb, h->stream));
     return HFPF_OK;
 }
 
@@ -428,12 +441,13 @@ int sort_keys_u32(hfpf_handle* h, uint32_t* in, uint32_t* out, uint64_t n)
 
 int sort_pairs_u64(hfpf_handle* h, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, uint64_t n)
 {
+    const unsigned kb = h->g.key_bits;
     size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, 64, h->stream));
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, kb, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
     bytes = h->sort_tmp.bytes;
-    HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0, 64, h->stream));
+    HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0, kb, h->stream));
     return HFPF_OK;
 }
 
@@ -475,17 +489,6 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     if (std::max(std::max(off_x, off_y), std::max(off_z, off_rgb)) + 4 > point_step)
         return fail(h, HFPF_ERR_BAD_ARG, "integrate: field offset beyond point_step");
     if (n_frames > 65535) return fail(h, HFPF_ERR_BAD_ARG, "integrate: at most 65535 frames per call");
-    if (h->binned && !h->bin_have_hist && n_frames > (uint32_t)kProbeFrames) {
-        // No plan for the per-brick bins yet (first call of a session): a short head of the batch goes through the direct forms
-        // and records the demand; the rest is binned with that demand scaled up.  One extra read-back, once per session.
-        int rc0 = integrate_device_locked(h, dev_base, kProbeFrames, frame_stride, n_points, point_step, off_x, off_y, off_z, off_rgb, poses, frame_ids);
-        if (rc0) return rc0;
-        if ((rc0 = read_counters(h))) return rc0;  // bricks the head allocated
-        return integrate_device_locked(h, (const char*)dev_base + (size_t)kProbeFrames * frame_stride, n_frames - kProbeFrames, frame_stride, n_points,
-                                       point_step, off_x, off_y, off_z, off_rgb, poses + 12 * (size_t)kProbeFrames,
-                                       frame_ids ? frame_ids + kProbeFrames : nullptr);
-    }
-    if ((uint64_t)blocks_for(n_points, 256) * n_frames >= 0xFFFFFFFFull) return fail(h, HFPF_ERR_BAD_ARG, "integrate: batch too large (split the call)");
     StageSlot* s = nullptr;
     int rc = acquire_stage(h, n_frames, &s);
     if (rc) return rc;
@@ -524,6 +527,33 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     }
     const bool color = h->t.color != 0;
     const bool bin = h->binned;
+    uint32_t launch_frames = n_frames, probe = 0;
+    if (bin && !h->bin_have_hist && n_frames > (uint32_t)kProbeFrames) {
+        // No plan for the per-brick bins yet (first batch of a session): a dry run of the batch's first frames claims their
+        // bricks and records the per-region demand, so that the real launch below parks from its first point.  One extra
+        // read-back (the brick count), once per session; batches of up to kProbeFrames frames just take the direct forms.
+        HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->t.bin_capb, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
+        launch_frames = kProbeFrames;
+        probe = 1;
+        const uint32_t log_rot = 0;
+        const dim3 pgrid((unsigned)std::min<uint64_t>((uint64_t)blocks_for(n_points, 256) * launch_frames, (uint64_t)h->integrate_grid));
+#define HFPF_LAUNCH_PROBE(P, C)                                                                                                                    \
+    hipLaunchKernelGGL((k_integrate<P, C, true>), pgrid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, \
+                       lay, (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w, log_rot, probe)
+        if (packed && !color) HFPF_LAUNCH_PROBE(true, false);
+        else if (packed && color) HFPF_LAUNCH_PROBE(true, true);
+        else if (!color) HFPF_LAUNCH_PROBE(false, false);
+        else HFPF_LAUNCH_PROBE(false, true);
+#undef HFPF_LAUNCH_PROBE
+        HIPCHK(h, hipGetLastError());
+        int rcp = read_counters(h);  // bricks the dry run claimed
+        if (rcp) return rcp;
+        h->bin_have_hist = true;
+        h->bin_prev_points = (double)n_points * kProbeFrames;
+        launch_frames = n_frames;
+        probe = 0;
+    }
     const uint32_t nb = (uint32_t)h->n_bricks_known;
     // a plan = per-brick bin regions sized from the previous launch's demand; without one nothing is parked (direct forms)
     const bool have_plan = bin && h->bin_have_hist && nb > 0;
@@ -558,8 +588,8 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     }
     const uint32_t log_rot = (uint32_t)((h->launch_seq++ * 17u) & (kLogRegions - 1));
 #define HFPF_LAUNCH_INTEGRATE(P, C, B)                                                                                                              \
-    hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, n_frames, lay, \
-                       (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w, log_rot)
+    hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, lay, \
+                       (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w, log_rot, probe)
     if (!bin) {
         if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, false);
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, false);
@@ -1205,7 +1235,7 @@ static int extract_locked(hfpf_handle* h, const unsigned long long* stats, const
     if ((rc = scratch(h, h->vals_a, n * 4))) return rc;
     if ((rc = scratch(h, h->vals_b, n * 4))) return rc;
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, h->stream, t.ctr, (int)C_ROWS, 0ull);
-    hipLaunchKernelGGL(k_extract_keys, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->g, t, stats, n, opt, (uint64_t*)h->keys_a.p, (uint32_t*)h->vals_a.p);
+    hipLaunchKernelGGL(k_extract_keys, dim3(blocks_for(n, 256 * kExtractTiles)), dim3(256), 0, h->stream, h->g, t, stats, n, opt, (uint64_t*)h->keys_a.p, (uint32_t*)h->vals_a.p);
     HIPCHK(h, hipGetLastError());
     if ((rc = sort_pairs_u64(h, (uint64_t*)h->keys_a.p, (uint64_t*)h->keys_b.p, (uint32_t*)h->vals_a.p, (uint32_t*)h->vals_b.p, n))) return rc;
     if ((rc = read_counters(h))) return rc;
@@ -1594,7 +1624,7 @@ int hfpf_get_occupied(hfpf_handle* h, int32_t* xyz, uint64_t cap, uint64_t* n_ou
     std::vector<uint64_t> keys(n);
     HIPCHK(h, hipMemcpyAsync(keys.data(), h->keys_b.p, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (uint64_t i = 0; i < std::min(n, cap); i++) key_coords(keys[i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    for (uint64_t i = 0; i < std::min(n, cap); i++) key_coords(h->g, keys[i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     return HFPF_OK;
 }
 

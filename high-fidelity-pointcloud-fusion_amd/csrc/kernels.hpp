@@ -120,8 +120,11 @@ template <bool PACKED16, bool COLOR, bool BIN>
 __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
-                                                   const uint32_t* __restrict__ frame_ids, const uint32_t row_w, const uint32_t log_rot)
+                                                   const uint32_t* __restrict__ frame_ids, const uint32_t row_w, const uint32_t log_rot,
+                                                   const uint32_t probe)
 {
+    // probe != 0: dry run of the batch's first frames for a session that has no bin plan yet -- transform, index, claim the
+    // bricks and record the per-region demand; nothing else is touched (the frames come again in the real launch).
     __shared__ unsigned long long queue[4][64 * kQueueStride];
     __shared__ unsigned int blk_ctr[6];
     __shared__ uint32_t s_occ_all[4][kOccStage];
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 
         // first occupancy (grid.hpp:219-243): the returning atomic on the brick's occupancy word decides who is first
         bool first = false;
-        if (act && !has_n) {
+        if (act && !has_n && !probe) {
             unsigned long long* om = reinterpret_cast<unsigned long long*>(&t.occ_mask[plane]);
             if (!(*om & bit)) {  // a stale (cached) word only sends the lane through the atomic
                 const unsigned long long old = atomicOr(om, (unsigned long long)bit);
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             base = __shfl(base, (int)grp_leader);
             cap = __shfl(cap, (int)grp_leader);
             roff = __shfl(roff, (int)grp_leader);
-            if (todo) {
+            if (todo && !probe) {
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
                     const uint64_t e = (uint64_t)roff + pos;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
                 }
             }
         }
-        if (__ballot(todo) == 0) continue;  // wave-uniform; the common case of the binned form
+        if (probe || __ballot(todo) == 0) continue;  // wave-uniform; the common case of the binned form
 
         // direct buffering; the viewpoint latch (smallest frame id that touched the cell, grid.hpp:229,238) is only ever
         // read before the normal exists
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
             if (cv[k]) atomicAdd(&blk_ctr[k], cv[k]);
     }
     __syncthreads();
-    if (threadIdx.x < 6 && blk_ctr[threadIdx.x]) atomicAdd(&t.ctr[C_PRESENTED + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
+    if (!probe && threadIdx.x < 6 && blk_ctr[threadIdx.x]) atomicAdd(&t.ctr[C_PRESENTED + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
 }
 
 
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t
                 const int total = __popcll(lo) + __popcll(hi);
                 if (total > g.gate) n_pass[tt] = 1;
                 else n_pend[tt] = 1;  // still without a normal: look at it again next pass (its neighbourhood may fill up)
-                key_[tt] = make_key(x, y, z);
+                key_[tt] = make_key(g, x, y, z);
             }
         }
     }
@@ -757,7 +760,7 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
     if (r >= n_cand) return;
     const uint64_t key = sorted_keys[r];
     int32_t x, y, z;
-    key_coords(key, x, y, z);
+    key_coords(g, key, x, y, z);
     const uint32_t slot = slot_lookup(g, t, x, y, z);
     uint64_t lo, hi;
     neighbourhood(g, t, x, y, z, lo, hi);
@@ -1215,26 +1218,37 @@ struct ExtractOpts {
     int32_t classify_threshold;  // < 0: off; else rows with count > threshold are painted red, the others white (grid.hpp:527-534)
     int32_t paint_white;         // 1: r = g = b = 255 as downloadHQ / downloadClassified set it (grid.hpp:527-529,558-560)
 };
+constexpr int kExtractTiles = 8;  // 256-record tiles per workgroup of k_extract_keys: one atomic on the row counter per workgroup
 __global__ __launch_bounds__(256) void k_extract_keys(const GridParams g, const Tables t, const unsigned long long* __restrict__ stats,
                                                       const uint64_t n_normals, const ExtractOpts opt, uint64_t* __restrict__ keys,
                                                       uint32_t* __restrict__ vals)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t valid = 0;
-    if (j < n_normals) {
+    __shared__ unsigned int s_rows;
+    if (threadIdx.x == 0) s_rows = 0;
+    __syncthreads();
+    uint32_t n_valid = 0;
+#pragma unroll
+    for (int tt = 0; tt < kExtractTiles; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kExtractTiles + tt) * 256u + threadIdx.x;
+        if (j >= n_normals) continue;
         const uint64_t nid = j + 1;
         const uint64_t key = t.nv_key[nid];
         int32_t x, y, z;
-        key_coords(key, x, y, z);
-        valid = valid_coord(g, x, y, z) ? 1u : 0u;
+        key_coords(g, key, x, y, z);
+        uint32_t valid = valid_coord(g, x, y, z) ? 1u : 0u;
         if (valid && opt.min_count > 0.0) {
             const long long cnt = (long long)stats[nid * kStatWords + SW_COUNT];
             if ((double)(int)cnt < opt.min_count) valid = 0;  // int count against a double threshold, grid.hpp:561
         }
         keys[j] = valid ? key : ~0ull;
         vals[j] = (uint32_t)nid;
+        n_valid += valid;
     }
-    wave_count(&t.ctr[C_ROWS], valid);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_valid += __shfl_down(n_valid, o);
+    if ((threadIdx.x & 63u) == 0 && n_valid) atomicAdd(&s_rows, n_valid);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rows) atomicAdd(&t.ctr[C_ROWS], (unsigned long long)s_rows);  // (one same-address device atomic costs ~12 ns)
 }
 
 struct Row {  // = hfpf_row
@@ -1256,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
     if (j >= n_rows) return;
     const uint64_t nid = vals[j];
     Row r;
-    key_coords(keys[j], r.ix, r.iy, r.iz);
+    key_coords(g, keys[j], r.ix, r.iy, r.iz);
     const long long* s = reinterpret_cast<const long long*>(&stats[nid * kStatWords]);
     const long long cnt = s[SW_COUNT];
     r.count = (uint32_t)cnt;
@@ -1322,7 +1336,7 @@ __global__ __launch_bounds__(256) void k_epoch_export(const GridParams g, const 
     int32_t x, y, z;
     slot_coords(g, t, slot, x, y, z);
     EpochRec r;
-    r.key = make_key(x, y, z);
+    r.key = make_key(g, x, y, z);
     r.first_frame = t.first_frame[slot];
     r.vx = r.vy = r.vz = 0.f;
     if (r.first_frame < t.max_frames) {
@@ -1350,7 +1364,7 @@ __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const 
         int32_t x = 0, y = 0, z = 0;
         if (want) {
             r = in[j];
-            key_coords(r.key, x, y, z);
+            key_coords(g, r.key, x, y, z);
             want = x <= g.dim[0] && y <= g.dim[1] && z <= g.dim[2];  // storage extent is dim+1 (grid.hpp:626)
         }
         const uint32_t bidx = want ? brick_index(g, x, y, z) : 0u;
@@ -1399,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_occupied_keys(const GridParams g, const
     if (j >= n_occ) return;
     int32_t x, y, z;
     slot_coords(g, t, t.occ_list[j], x, y, z);
-    keys[j] = make_key(x, y, z);
+    keys[j] = make_key(g, x, y, z);
 }
 
 // ---- leaf probes (tests only; same device functions as the kernels above) -------------------------

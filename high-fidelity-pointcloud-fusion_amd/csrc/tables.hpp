@@ -137,12 +137,15 @@ struct Tables {
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-HFPF_HD uint64_t make_key(int32_t x, int32_t y, int32_t z) { return ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z; }
-HFPF_HD void key_coords(uint64_t k, int32_t& x, int32_t& y, int32_t& z)
+HFPF_HD uint64_t make_key(const GridParams& g, int32_t x, int32_t y, int32_t z)
 {
-    x = (int32_t)(k >> 42);
-    y = (int32_t)((k >> 21) & 0x1FFFFF);
-    z = (int32_t)(k & 0x1FFFFF);
+    return ((uint64_t)x << g.key_sx) | ((uint64_t)y << g.key_sy) | (uint64_t)z;
+}
+HFPF_HD void key_coords(const GridParams& g, uint64_t k, int32_t& x, int32_t& y, int32_t& z)
+{
+    x = (int32_t)(k >> g.key_sx);
+    y = (int32_t)((k >> g.key_sy) & ((1ull << (g.key_sx - g.key_sy)) - 1ull));
+    z = (int32_t)(k & ((1ull << g.key_sy) - 1ull));
 }
 HFPF_HD uint32_t brick_index(const GridParams& g, int32_t x, int32_t y, int32_t z)
 {

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _props(rows, ctr, dims):
-    key = rows["ix"].astype(np.int64) * (1 << 42) + rows["iy"].astype(np.int64) * (1 << 21) + rows["iz"]
+    key = rows["ix"].astype(np.int64) * (1 << 42) + rows["iy"].astype(np.int64) * (1 << 21) + rows["iz"]  # any order-preserving packing
     assert (np.diff(key) > 0).all(), "rows not in strict lexicographic (x,y,z) order"
     assert (rows["ix"] < dims[0]).all() and (rows["iy"] < dims[1]).all() and (rows["iz"] < dims[2]).all()
     assert ctr["points_zclip_pass"] <= ctr["points_presented"] and ctr["points_in_bbox"] <= ctr["points_zclip_pass"]
