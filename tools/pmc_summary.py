@@ -5,9 +5,10 @@ the integrate hot path: k_integrate (decode / clip / transform / insert / park) 
 usage: python tools/pmc_summary.py gpurun_out/<prefix> profiles/r02_pmc_hot_path
 
 Each pass ran `bench.py --repeats 1 --warmup 0 --cpu-sample 0 --host-path-frames 0`: the 1000-frame configs[1] stream, one
-hfpf_integrate_device call per clean epoch.  k_integrate dispatches: #0 = the first epoch (everything is buffered, no dependant
-exists yet), #1..#5 = steady state, 150 frames each (#6 is the 100-frame tail and is left out of the per-launch means);
-k_update dispatches #0..#4 belong to the steady launches #1..#5.
+hfpf_integrate_device call per clean epoch.  k_integrate dispatches: #0 = the dry run of the session's first 8 frames (bin
+demand), #1 = the first epoch (everything is buffered, no dependant exists yet), #2..#6 = steady state, 150 frames each (#7 is
+the 100-frame tail and is left out of the per-launch means); k_update dispatches #0..#4 belong to the steady launches;
+k_buffer dispatch #0 to the first epoch, #1..#5 to the steady launches.
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of a wide
 (16 B/lane) coalesced stream, so 8 B per streamed 16-byte record are added (the frame read in k_integrate, the bin read-back in
 k_update); narrower scattered reads are uncalibrated.
@@ -40,7 +41,7 @@ def load(prefix):
     for f in sorted(glob.glob(prefix + "_*/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            which = "k_integrate" if "k_integrate" in k else ("k_update" if "k_update" in k else None)
+            which = "k_integrate" if "k_integrate" in k else ("k_update" if "k_update" in k else ("k_buffer" if "k_buffer" in k else None))
             if which:
                 per[which][r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
     return per
@@ -59,20 +60,25 @@ def main():
     pts = FRAMES_PER_LAUNCH * NPTS
     res = {"source_sha": source_sha(), "points_per_launch": pts, "frames_per_launch": FRAMES_PER_LAUNCH,
            "source": "rocprofv3 --pmc, separate passes (tools/pmc_passes.sh), bench.py --repeats 1 --warmup 0"}
-    for phase, sel_a, sel_b in (("first_epoch_buffer_only", lambda v: v[:1], None),
-                                ("steady_state_after_first_clean", lambda v: v[1:6], lambda v: v[:5])):
+    for phase, sel_a, sel_b, sel_c in (("first_epoch_buffer_only", lambda v: v[1:2], None, lambda v: v[:1]),
+                                       ("steady_state_after_first_clean", lambda v: v[2:7], lambda v: v[:5], lambda v: v[1:6])):
         ga = lambda c: mean(sel_a(series(per, "k_integrate", c)))
         gb = (lambda c: mean(sel_b(series(per, "k_update", c)))) if sel_b else (lambda c: 0.0)
+        gc = lambda c: mean(sel_c(series(per, "k_buffer", c)))
         fa, wa, aa = ga("FETCH_SIZE") * 1024, ga("WRITE_SIZE") * 1024, ga("TCC_EA0_ATOMIC_sum")
         fb, wb, ab = gb("FETCH_SIZE") * 1024, gb("WRITE_SIZE") * 1024, gb("TCC_EA0_ATOMIC_sum")
-        corr = 0.5 * 16 * pts + (0.5 * 16 * in_bbox_frac * pts if sel_b else 0.0)
-        traffic = fa + fb + corr + wa + wb
+        fc, wc, ac = gc("FETCH_SIZE") * 1024, gc("WRITE_SIZE") * 1024, gc("TCC_EA0_ATOMIC_sum")
+        # wide-read correction: the frame stream (all points), the bin read-back of k_update (steady state: the in-bbox points) or
+        # of k_buffer (first epoch: the in-bbox points, all of them buffered)
+        corr = 0.5 * 16 * pts + 0.5 * 16 * in_bbox_frac * pts
+        traffic = fa + fb + fc + corr + wa + wb + wc
         hit = lambda g: g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1.0)
         res[phase] = {
             "k_integrate": {"fetch_bytes_raw": fa, "write_bytes": wa, "atomic_requests": aa, "l2_hit_rate": hit(ga)},
             "k_update": {"fetch_bytes_raw": fb, "write_bytes": wb, "atomic_requests": ab, "l2_hit_rate": hit(gb) if sel_b else None},
+            "k_buffer": {"fetch_bytes_raw": fc, "write_bytes": wc, "atomic_requests": ac, "l2_hit_rate": hit(gc)},
             "fetch_correction_bytes": corr,
-            "atomic_requests": aa + ab,
+            "atomic_requests": aa + ab + ac,
             "traffic_bytes_per_launch": traffic,
             "traffic_bytes_per_point": traffic / pts,
             "algorithmic_bytes_per_launch": 32 * pts,
@@ -85,7 +91,7 @@ def main():
                 "+8 B per streamed 16-byte record (gfx950 tallies wide coalesced reads at half); scattered 4-8 B table reads are uncalibrated.\n\n" % (FRAMES_PER_LAUNCH, pts))
         f.write("| phase | kernel | FETCH raw | WRITE | atomic requests | L2 hit rate |\n|---|---|---|---|---|---|\n")
         for phase in ("first_epoch_buffer_only", "steady_state_after_first_clean"):
-            for k in ("k_integrate", "k_update"):
+            for k in ("k_integrate", "k_update", "k_buffer"):
                 r = res[phase][k]
                 if r["l2_hit_rate"] is None:
                     continue

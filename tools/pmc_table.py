@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Mean counter value per kernel launch from the passes of tools/pmc_passes.sh.
-usage: python tools/pmc_table.py gpurun_out/<prefix> [kernel-substring ...]   (steady-state launches: the first one of each kernel is skipped
-when the kernel ran more than twice)"""
+usage: python tools/pmc_table.py gpurun_out/<prefix> [kernel-substring ...]
+Steady-state launches only: of k_integrate the first two dispatches (dry run, first epoch) and the last (100-frame tail) are left
+out, of k_buffer the first (first epoch) and the last, of k_update the last; other kernels: all dispatches."""
 import collections
 import csv
 import glob
@@ -19,7 +20,8 @@ def main():
                 if w in r["Kernel_Name"]:
                     per[(w, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (w, c), v in per.items():
-            vv = v[1:] if len(v) > 2 else v
+            lo, hi = {"k_integrate": (2, -1), "k_buffer": (1, -1), "k_update": (0, -1)}.get(w, (0, None))
+            vv = v[lo:hi] if len(v) > lo + 2 else v
             rows[(w, c)] = sum(vv) / len(vv)
     print("| kernel | counter | mean per steady-state launch |\n|---|---|---|")
     for (w, c), v in rows.items():
