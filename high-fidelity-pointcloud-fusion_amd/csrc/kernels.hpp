@@ -53,9 +53,10 @@ constexpr int kListTiles = 4;  // same idea for the k_depinc_* list builders (no
 typedef float vf4 __attribute__((ext_vector_type(4)));  // native vector type (the nontemporal builtins do not take HIP's float4)
 
 // Wave-cooperative flush of statistic deltas: lanes with `member` park their delta (5 words, + 3 colour sums, + record id)
-// in the wave's LDS queue, then the wave replays the queue with 8 lanes per record, so one wave-instruction
-// carries 8 whole 64-byte records (one memory-side atomic segment each).  Convergent (all 64 lanes must call).
+// in the wave's LDS queue, kQueueRows at a time, and the wave replays the queue with 8 lanes per record, so one
+// wave-instruction carries 8 whole 64-byte records (one memory-side atomic segment each).  Convergent (all 64 lanes must call).
 constexpr int kQueueStride = 11;  // u64 words per queued delta; odd stride spreads LDS banks
+constexpr int kQueueRows = 8;     // deltas staged per round (the queue is 704 bytes per wave: the direct form is the rare path)
 template <bool COLOR>
 __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned long long* q, bool member, const StatDeltaT<COLOR>& d, uint32_t sid)
 {
@@ -64,33 +65,32 @@ __device__ __forceinline__ void wave_flush_members(const Tables& t, unsigned lon
     if (mm == 0) return;
     const uint32_t lane = lane_id();
     const uint32_t n_mem = (uint32_t)__popcll(mm);
-    if (member) {
-        const uint32_t row = (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-        unsigned long long* r = q + row * kQueueStride;
+    const uint32_t rank = (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+    for (uint32_t r0 = 0; r0 < n_mem; r0 += (uint32_t)kQueueRows) {  // wave-uniform trip count
+        if (member && rank >= r0 && rank < r0 + (uint32_t)kQueueRows) {
+            unsigned long long* r = q + (rank - r0) * kQueueStride;
 #pragma unroll
-        for (int w = 0; w < kStatUsed; w++) r[w] = (unsigned long long)d.v[w];
-        if constexpr (COLOR) {
-            r[SW_R] = (unsigned long long)d.rgb[0];
-            r[SW_G] = (unsigned long long)d.rgb[1];
-            r[SW_B] = (unsigned long long)d.rgb[2];
+            for (int w = 0; w < kStatUsed; w++) r[w] = (unsigned long long)d.v[w];
+            if constexpr (COLOR) {
+                r[SW_R] = (unsigned long long)d.rgb[0];
+                r[SW_G] = (unsigned long long)d.rgb[1];
+                r[SW_B] = (unsigned long long)d.rgb[2];
+            }
+            r[8] = sid;
         }
-        r[8] = sid;
-    }
-    // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        const uint32_t w = lane & 7u;
-        for (uint32_t r0 = 0; r0 < n_mem; r0 += 8) {
-            const uint32_t row = r0 + (lane >> 3);
-            if (row < n_mem && w < (uint32_t)W) {
+        // same-wave LDS hand-off: DS operations of one wave execute in order; the fences only pin the compiler
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const uint32_t w = lane & 7u, row = lane >> 3;
+            if (r0 + row < n_mem && w < (uint32_t)W) {
                 const unsigned long long* r = q + row * kQueueStride;
                 atomicAdd(&t.stats[(uint64_t)r[8] * kStatWords + w], r[w]);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 constexpr int kOccStage = 256;  // newly occupied cells ONE WAVE of k_integrate stages before appending them to occ_list
@@ -116,8 +116,13 @@ __device__ __forceinline__ void flush_occ_stage(const Tables& t, const uint32_t*
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Seven waves per SIMD (<= 72 VGPRs, no scratch): the tile loop is a chain of dependent table round trips, so resident waves are
+// what hides them; eight would spill.
+#ifndef HFPF_INT_WAVES
+#define HFPF_INT_WAVES 7
+#endif
 template <bool PACKED16, bool COLOR, bool BIN>
-__global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
+__global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
                                                    const uint32_t* __restrict__ frame_ids, const uint32_t row_w, const uint32_t log_rot,
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
 {
     // probe != 0: dry run of the batch's first frames for a session that has no bin plan yet -- transform, index, claim the
     // bricks and record the per-region demand; nothing else is touched (the frames come again in the real launch).
-    __shared__ unsigned long long queue[4][64 * kQueueStride];
+    __shared__ unsigned long long queue[4][kQueueRows * kQueueStride];
     __shared__ unsigned int blk_ctr[6];
     __shared__ uint32_t s_occ_all[4][kOccStage];
     const uint32_t lane = threadIdx.x & 63u;
@@ -215,30 +220,47 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         c_in += act;
 
         const uint32_t bidx = act ? brick_index(g, ix, iy, iz) : 0u;
-        const uint32_t b = brick_acquire_wave(t, bidx, act);
+        uint32_t dir_word = 0;
+        if (act) dir_word = t.dir[bidx];  // issued here, needed after the grouping loop below
+        // Lanes of the same brick, as a mask per lane (registers and scalar lane reads only): the loop runs while the directory
+        // read is in flight, and the bin reservation further down needs no loop of its own.
+        unsigned long long same_brick = 0;
+        if (BIN) {
+            unsigned long long m = __ballot(act);
+            while (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bidx, leader);
+                const bool same = act && bidx == lb;
+                const unsigned long long sm = __ballot(same);
+                if (same) same_brick = sm;
+                m &= ~sm;
+            }
+        }
+        const uint32_t b = brick_acquire_wave(t, bidx, act, dir_word);
         act = act && b != 0;
         const uint32_t lcell = local_index(ix, iy, iz);
         const uint32_t slot = b * kBrickCells + lcell;
         // What to do with the point is two bits of its cell: normal_found (stop buffering, grid.hpp:210) and has-dependants.
-        // Both come from the brick's 128-byte flag line (L2-resident) instead of the cell's 8-byte info word.
+        // Both come from the brick's 128-byte flag line (L2-resident) instead of the cell's 8-byte info word.  The occupancy
+        // word of the cell's plane is read in the same round trip (it is only needed while the cell has no normal).
         const uint64_t plane = (uint64_t)b * 8u + ((uint32_t)ix & 7u);
         const uint64_t bit = 1ull << ((((uint32_t)iy & 7u) << 3) | ((uint32_t)iz & 7u));
         bool has_n = false, has_d = false;
+        unsigned long long occ_word = ~0ull;
         if (act) {
             const ulonglong2 nd = *reinterpret_cast<const ulonglong2*>(&t.nd_mask[plane * 2]);
+            occ_word = *reinterpret_cast<const unsigned long long*>(&t.occ_mask[plane]);
             has_n = (nd.x & bit) != 0;
             has_d = (nd.y & bit) != 0;
         }
 
         // first occupancy (grid.hpp:219-243): the returning atomic on the brick's occupancy word decides who is first
         bool first = false;
-        if (act && !has_n && !probe) {
+        if (act && !has_n && !probe && !(occ_word & bit)) {  // a stale (cached) word only sends the lane through the atomic
             unsigned long long* om = reinterpret_cast<unsigned long long*>(&t.occ_mask[plane]);
-            if (!(*om & bit)) {  // a stale (cached) word only sends the lane through the atomic
-                const unsigned long long old = atomicOr(om, (unsigned long long)bit);
-                first = !(old & bit);
-                if (first) atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
-            }
+            const unsigned long long old = atomicOr(om, (unsigned long long)bit);
+            first = !(old & bit);
+            if (first) atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
         }
         // newly occupied cells are staged in LDS (per wave) and appended to occ_list in batches: C_OCC is one address for the
         // whole chip (a same-address atomic retires every ~12 ns), so it gets one atomic per flush, not one per tile.  The
@@ -264,23 +286,14 @@ __global__ __launch_bounds__(256) void k_integrate(const GridParams g, const Tab
         bool todo = act && (has_d || !has_n);
         if (BIN) {
             const bool want_bin = todo;
-            // phase 1 (registers only): group the lanes by bin region (brick x {cell has a normal, cell has none}) -> leader
-            // lane, rank in group, group size
+            // phase 1 (registers only): the lane's group = the lanes of its bin region (brick x {cell has a normal, cell has
+            // none}) -> leader lane, rank in group, group size
             const uint32_t rg = 2u * b + (has_n ? 0u : 1u);
-            uint32_t grp_leader = lane, grp_rank = 0, grp_size = 0;
-            unsigned long long m = __ballot(want_bin);
-            while (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                const uint32_t lb = __shfl(rg, leader);
-                const bool same = want_bin && rg == lb;
-                const unsigned long long sm = __ballot(same);
-                if (same) {
-                    grp_leader = (uint32_t)leader;
-                    grp_rank = (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-                    grp_size = (uint32_t)__popcll(sm);
-                }
-                m &= ~sm;
-            }
+            const unsigned long long hn = __ballot(has_n);
+            const unsigned long long grp = same_brick & __ballot(want_bin) & (has_n ? hn : ~hn);
+            const uint32_t grp_leader = want_bin ? (uint32_t)(__ffsll((long long)grp) - 1) : lane;
+            const uint32_t grp_rank = (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+            const uint32_t grp_size = (uint32_t)__popcll(grp);
             // phase 2: every group leader reserves for its group in ONE wave-instruction (one memory round trip per tile);
             // the counter also records the demand the next launch's plan is made from
             uint32_t base = 0, cap = 0, roff = 0;
@@ -903,7 +916,7 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint64_t n_touched, const uint64_t base)
 {
-    __shared__ unsigned long long queue[4][64 * kQueueStride];
+    __shared__ unsigned long long queue[4][kQueueRows * kQueueStride];
     unsigned long long* q = queue[threadIdx.x >> 6];
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t j = gid / kChains;           // cell

@@ -234,10 +234,10 @@ __device__ inline uint32_t brick_acquire_single(const Tables& t, uint32_t bidx)
 // Wave-level election: every lane that needs a brick which is not there yet takes part; one lane per
 // distinct directory entry runs the claim, the others receive its id through a shuffle.
 // Must be reached by all 64 lanes of the wave (convergent); `want` masks the lanes with real work.
-__device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bool want)
+// `v` = the lane's directory word, read by the caller with a plain (cacheable) load (0 for lanes that do not want a brick); a
+// stale 0 only sends the lane through the atomic path.
+__device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bool want, uint32_t v)
 {
-    uint32_t v = 0;
-    if (want) v = t.dir[bidx];  // plain (cacheable) load; a stale 0 only sends the lane through the atomic path
     bool need = want && (v == 0 || v == kLock);
     unsigned long long m = __ballot(need);
     const uint32_t lane = lane_id();
@@ -254,6 +254,12 @@ __device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bo
         m = __ballot(need);
     }
     return v;
+}
+__device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bool want)
+{
+    uint32_t v = 0;
+    if (want) v = t.dir[bidx];
+    return brick_acquire_wave(t, bidx, want, v);
 }
 
 // Wave-aggregated bump allocation: one atomic per wave, ranks by prefix popcount of the ballot.
