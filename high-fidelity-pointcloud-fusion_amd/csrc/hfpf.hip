@@ -11,7 +11,12 @@
 
 #include <dlfcn.h>
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -59,6 +64,105 @@ struct FrameSlot {  // host-frame staging (pinned + device)
     bool pending = false;
 };
 
+// Helper threads for the bounce copy of hfpf_integrate (caller's pageable frame -> pinned staging): one core moves ~12 GB/s, the
+// link takes 55, so the copy is split over the caller + the helpers.  The helpers spin for a fraction of a millisecond after a
+// job (a stream of frames keeps them hot) and sleep on a condition variable otherwise.
+// Copy with non-temporal stores (dst 16-byte aligned): the staging buffer is only read by the DMA engine afterwards, so the
+// lines need not be fetched for ownership nor kept in the cache -- a third less memory traffic than memcpy below glibc's
+// non-temporal threshold (which a 1-2 MB share of a frame does not reach).
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline void stream_copy(char* dst, const char* src, size_t n)
+{
+    if (((uintptr_t)dst & 15u) != 0) {
+        memcpy(dst, src, n);
+        return;
+    }
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 32)), d = _mm_loadu_si128((const __m128i*)(src + i + 48));
+        _mm_stream_si128((__m128i*)(dst + i), a);
+        _mm_stream_si128((__m128i*)(dst + i + 16), b);
+        _mm_stream_si128((__m128i*)(dst + i + 32), c);
+        _mm_stream_si128((__m128i*)(dst + i + 48), d);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+#else
+inline void stream_copy(char* dst, const char* src, size_t n) { memcpy(dst, src, n); }
+#endif
+
+class StagePool {
+  public:
+    explicit StagePool(int helpers)
+    {
+        for (int i = 0; i < helpers; i++) th_.emplace_back([this, i] { run(i + 1); });
+    }
+    ~StagePool()
+    {
+        stop_.store(true, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            cv_.notify_all();
+        }
+        for (auto& t : th_) t.join();
+    }
+    void copy(void* dst, const void* src, size_t bytes)
+    {
+        dst_ = (char*)dst, src_ = (const char*)src, bytes_ = bytes;
+        remaining_.store((int)th_.size(), std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> lk(m_);
+            cv_.notify_all();
+        }
+        part(0);
+        while (remaining_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    }
+
+  private:
+    void part(int i) const
+    {
+        const size_t parts = th_.size() + 1;
+        const size_t chunk = ((bytes_ + parts - 1) / parts + 4095) & ~(size_t)4095;
+        const size_t lo = std::min(bytes_, chunk * (size_t)i), hi = std::min(bytes_, lo + chunk);
+        if (hi > lo) stream_copy(dst_ + lo, src_ + lo, hi - lo);
+    }
+    void run(int i)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t g;
+            int spins = 0;
+            while ((g = gen_.load(std::memory_order_acquire)) == seen && !stop_.load(std::memory_order_acquire)) {
+                if (++spins < 20000) {
+                    __builtin_ia32_pause();
+                } else {
+                    std::unique_lock<std::mutex> lk(m_);
+                    sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire); });
+                    sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+                    spins = 0;
+                }
+            }
+            if (stop_.load(std::memory_order_acquire)) return;
+            seen = g;
+            part(i);
+            remaining_.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> remaining_{0}, sleepers_{0};
+    std::atomic<bool> stop_{false};
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t bytes_ = 0;
+};
+
 constexpr int kStageSlots = 8;
 constexpr int kProbeFrames = 8;  // frames of a plan-less batch that go ahead of the rest to measure the per-brick demand
 constexpr int kFrameSlots = 8;  // uploads run ahead of the kernels by up to this many frames
@@ -101,6 +205,8 @@ struct hfpf_handle {
     StageSlot stage[kStageSlots];
     int stage_next = 0;
     FrameSlot fslot[kFrameSlots];
+    StagePool* stage_pool = nullptr;  // created by the first large bounce copy (HFPF_STAGE_THREADS helpers, default 4; 0 = none)
+    int stage_threads = -1;
     int fslot_next = 0;
 
     // scratch
@@ -1093,6 +1199,8 @@ int hfpf_destroy(hfpf_handle* h)
         if (s.d_ids) (void)hipFree(s.d_ids);
         if (s.done) (void)hipEventDestroy(s.done);
     }
+    delete h->stage_pool;
+    h->stage_pool = nullptr;
     for (auto& f : h->fslot) {
         if (f.h) (void)hipHostFree(f.h);
         if (f.d) (void)hipFree(f.d);
@@ -1176,7 +1284,18 @@ static int integrate_host_locked(hfpf_handle* h, const void* base, bool bounce, 
             HIPCHK(h, hipHostMalloc(&f.h, cap, hipHostMallocDefault));
             f.cap_h = cap;
         }
-        memcpy(f.h, base, bytes);  // the caller's buffer is free again when this call returns
+        // the caller's buffer is free again when this call returns
+        if (h->stage_threads < 0) {
+            const char* e = getenv("HFPF_STAGE_THREADS");
+            const int hw = (int)std::thread::hardware_concurrency();
+            h->stage_threads = e ? std::max(0, std::min(atoi(e), 15)) : std::max(0, std::min(4, hw / 2 - 1));
+        }
+        if (h->stage_threads > 0 && bytes >= (1u << 20)) {
+            if (!h->stage_pool) h->stage_pool = new StagePool(h->stage_threads);
+            h->stage_pool->copy(f.h, base, bytes);
+        } else {
+            stream_copy((char*)f.h, (const char*)base, bytes);
+        }
         src = f.h;
     }
     HIPCHK(h, hipMemcpyAsync(f.d, src, bytes, hipMemcpyHostToDevice, h->copy_stream));
