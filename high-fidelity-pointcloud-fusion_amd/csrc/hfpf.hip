@@ -205,6 +205,7 @@ struct hfpf_handle {
     StageSlot stage[kStageSlots];
     int stage_next = 0;
     FrameSlot fslot[kFrameSlots];
+    bool update_cells = true;  // k_update_cells (cell-sorted form); HFPF_UPDATE_FORM=points: k_update (per-point form), A/B and tests
     StagePool* stage_pool = nullptr;  // created by the first large bounce copy (HFPF_STAGE_THREADS helpers, default 4; 0 = none)
     int stage_threads = -1;
     int fslot_next = 0;
@@ -748,8 +749,13 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         else HFPF_LAUNCH_INTEGRATE(false, true, true);
         if (have_plan) {
             if (h->h_ctr[C_NORMALS] > 0) {  // as of the last clean: without a normal record no cell has dependants
-                if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
-                else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
+                if (h->update_cells) {
+                    if (color) hipLaunchKernelGGL(k_update_cells<true>, dim3(nb), dim3(kUpd2Threads), 0, h->stream, h->g, h->t, nb);
+                    else hipLaunchKernelGGL(k_update_cells<false>, dim3(nb), dim3(kUpd2Threads), 0, h->stream, h->g, h->t, nb);
+                } else {
+                    if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
+                    else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
+                }
             }
             if (color) hipLaunchKernelGGL(k_buffer<true>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
             else hipLaunchKernelGGL(k_buffer<false>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
@@ -1144,6 +1150,8 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         return bail(fail(h, HFPF_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)));
     memset(h->h_log_ctr, 0, kLogRegions * 16 * sizeof(unsigned long long));
     {
+        const char* uf = getenv("HFPF_UPDATE_FORM");
+        h->update_cells = !(uf && uf[0] == 'p');
         const char* mb = getenv("HFPF_MAILBOX");
         if (!mb || mb[0] != '0') {
             if ((e = hipHostMalloc((void**)&h->mbox, (kMboxWords + 8) * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)

@@ -1,14 +1,17 @@
 // csrc/kernels.hpp -- HIP kernels of the fusion path (gfx950, 64-wide waves).
 //
-//   K1 k_integrate        decode + z-clip + SE(3) + bbox clip + voxel index + brick claim + insert/append; points whose cell
-//                         has dependants are parked in their brick's bin (node.cpp:190-214,251-255,289; grid.hpp:194-243)
-//   K2 k_update           dependant updates per brick: LDS-staged statistic records, one flush per record (grid.hpp:244-277)
-//      (k_integrate<.., BIN=false> keeps the direct form: one memory-side atomic per (point, dependant) pair)
+//   K1 k_integrate        decode + z-clip + SE(3) + bbox clip + voxel index + brick claim + first occupancy; what is left to do
+//                         with a point (buffer it / update its cell's dependants) is parked in its brick's bin, region A
+//                         (cell has a normal) or B (it has none) (node.cpp:190-214,251-255,289; grid.hpp:194-243)
+//   K2 k_update           region A: dependant updates per brick, LDS-staged statistic records, one flush per record (grid.hpp:244-277)
+//      k_buffer           region B: the brick's buffered points go to the point log as one run, chained per cell (grid.hpp:210-211,230,239)
+//      (k_integrate<.., BIN=false>, and lanes whose bin region is full, keep the direct forms: log append + one memory-side
+//      atomic segment per (point, dependant) pair)
 //      k_bin_plan/clamp   per-brick bin regions of the next launch from the previous launch's demand
 //   K3 k_gate             5x5x5 occupancy count and the >gate test            (grid.hpp:322-352)
 //   K4 k_normal           plane fit on occupied neighbour centres, orientation (grid.hpp:356-398)
 //   K5 k_register         +-K line walk, dependant registration (grid.hpp:403-417,443-449)
-//      k_link_log         chains the point-log entries appended since the last clean (4 interleaved chains per cell)
+//      k_link_log         chains the point-log entries the direct form appended since the last clean (4 interleaved chains per cell)
 //      k_replay           buffer replay of the cells that gained registrants (grid.hpp:418-440)
 //      k_depinc_*/k_dep_* incremental update / compacting rebuild of the per-cell dependant table
 //   K6 k_extract_*        ordered compaction of normal_found voxels            (grid.hpp:463-480)
@@ -32,8 +35,8 @@ struct FrameLayout {
 // point log is striped over kLogRegions append regions with one counter per 128-byte line.
 //
 // Dependant updates, direct form (BIN = false, and the fallback of the binned form): every (point, dependant) pair
-// inside the 1 mm cylinder adds 7 int64 words to ONE 64-byte statistics record.  A lane-per-pair loop would issue 7
-// fully scattered atomic instructions per round (448 memory-side requests); instead the member lanes park their deltas
+// inside the 1 mm cylinder adds 5 int64 words (8 with colour) to ONE 64-byte statistics record.  A lane-per-pair loop would issue
+// as many fully scattered atomic instructions per round (320 memory-side requests); instead the member lanes park their deltas
 // in a per-wave LDS queue and the wave replays the queue with 8 lanes per record, so one wave-instruction carries 8 whole
 // records as one 64-byte segment each.  That form saturates the chip's ~20 G requests/s atomic unit (41 M per launch).
 // Binned form (BIN = true, default): the point is parked in its brick's bin and k_update does the pairs brick by brick.
@@ -521,6 +524,234 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
     }
     __syncthreads();
     // striped like k_replay's counter: words 2 and 3 of the 64 log_ctr lines, summed by the host
+    if (tid < 2 && blk_ctr[tid])
+        atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2, cell-sorted form.  The per-point form above reads a 32-byte dependant entry from global memory and does five LDS atomics
+// for EVERY (point, dependant) pair.  Here the brick's parked points are counting-sorted by cell into LDS (kUpd2Cap at a time),
+// and a work item is (cell, dependant entry, run of up to kUpd2Chunk of the cell's points): the entry is read once per item, the
+// points come from LDS (lanes of one cell read the same address), the contributions are summed in registers (int32: one is below
+// 2^27, stats.hpp) and the item ends with ONE hash insert + five LDS atomics.  Same LDS record table and flush as above; the
+// sums are integers, so the result is bit-identical whatever the order.
+#ifndef HFPF_UPD2_THREADS
+#define HFPF_UPD2_THREADS 512
+#endif
+#ifndef HFPF_UPD2_CAP
+#define HFPF_UPD2_CAP 1024  // points sorted per round (LDS: 16 bytes each)
+#endif
+#ifndef HFPF_UPD2_CHUNK
+#define HFPF_UPD2_CHUNK 8  // points of a cell one work item takes
+#endif
+constexpr int kUpd2Threads = HFPF_UPD2_THREADS, kUpd2Cap = HFPF_UPD2_CAP, kUpd2Chunk = HFPF_UPD2_CHUNK;
+static_assert(kUpd2Threads == 256 || kUpd2Threads == 512 || kUpd2Threads == 1024, "k_update_cells: one or two cells per scanning thread");
+static_assert(kUpd2Cap % kUpd2Threads == 0 && kUpd2Chunk >= 1 && kUpd2Chunk <= 15, "k_update_cells: int32 item sums hold 15 contributions");
+
+template <bool COLOR>
+__global__ __launch_bounds__(kUpd2Threads) void k_update_cells(const GridParams g, const Tables t, const uint32_t n_bricks)
+{
+    constexpr int W = COLOR ? 8 : kStatUsed;
+    constexpr uint32_t T = kUpd2Threads, NW = T / 64, CPT = T >= kBrickCells ? 1 : kBrickCells / T, PER = kUpd2Cap / T, CH = kUpd2Chunk;
+    __shared__ float4 s_pts[kUpd2Cap];
+    __shared__ uint32_t s_rgb[COLOR ? kUpd2Cap : 1];
+    __shared__ uint64_t s_info[kBrickCells];
+    __shared__ uint32_t s_cnt[kBrickCells];
+    __shared__ uint32_t s_start[kBrickCells + 1];  // first sorted position of each cell's points
+    __shared__ uint32_t s_items[kBrickCells + 1];  // first work item of each cell
+    __shared__ uint32_t s_wsum[2][NW];
+    __shared__ uint32_t keys[kUpdSlots];
+    __shared__ unsigned long long vals[kUpdSlots * W];
+    __shared__ unsigned int blk_ctr[2];
+    const uint32_t b = blockIdx.x + 1;
+    if (b > n_bricks) return;
+    const uint32_t fill_a = min(t.bin_fill[2 * b], t.bin_capb[2 * b]), fill_b = min(t.bin_fill[2 * b + 1], t.bin_capb[2 * b + 1]);
+    const uint32_t fill = fill_a + fill_b;
+    if (fill == 0) return;  // block-uniform
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t first_a = t.bin_off[2 * b], first_b = t.bin_off[2 * b + 1];
+    auto entry = [&](uint32_t i) -> uint64_t { return i < fill_a ? first_a + i : first_b + (i - fill_a); };
+    for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += T) s_info[i] = t.info[(uint64_t)b * kBrickCells + i];
+    for (uint32_t i = tid; i < (uint32_t)kUpdSlots; i += T) keys[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t)(kUpdSlots * W); i += T) vals[i] = 0;
+    if (tid < 2) blk_ctr[tid] = 0;
+    const float4* __restrict__ dep4 = reinterpret_cast<const float4*>(t.dep);
+    uint32_t c_tested = 0, c_member = 0;
+    // Software pipeline: the points of round r+1 are read from the bin while round r's items are worked, and an item's dependant
+    // entry is read one item ahead (the first one of a round right after the scan, ahead of the scatter).
+    float4 pt[PER];
+    uint32_t col[PER];
+    auto load_round = [&](uint32_t r0) {
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t i = r0 + tid + k * T;
+            col[k] = 0;
+            pt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < fill) {
+                pt[k] = t.bin_pt[entry(i)];
+                if (COLOR) col[k] = t.bin_rgb[entry(i)];
+            }
+        }
+    };
+    struct Item {
+        uint32_t first, p_lo, p_hi;
+        float4 e0, e1;
+    };
+    auto locate = [&](uint32_t item, Item& it) {  // work item -> (cell, entry, run of points) + the entry's two 16-byte halves
+        uint32_t lo = 0, hi = kBrickCells;  // s_items[lo] <= item < s_items[hi]
+#pragma unroll
+        for (int st = 0; st < 9; st++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_items[mid] <= item) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t local = item - s_items[lo];
+        it.first = s_start[lo];
+        const uint32_t n_c = s_start[lo + 1] - it.first;
+        const uint32_t chunks = (n_c + CH - 1) / CH;
+        const uint32_t j = local / chunks, ch = local - j * chunks;
+        const uint64_t off = s_info[lo] >> kDepOffShift;
+        it.e0 = dep4[2 * (off + j)];
+        it.e1 = dep4[2 * (off + j) + 1];
+        it.p_lo = ch * CH;
+        it.p_hi = min(n_c, it.p_lo + CH);
+    };
+    load_round(0);
+    for (uint32_t r0 = 0; r0 < fill; r0 += (uint32_t)kUpd2Cap) {  // block-uniform trip count
+        const uint32_t n_round = min((uint32_t)kUpd2Cap, fill - r0);
+        for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += T) s_cnt[i] = 0;
+        __syncthreads();
+        // rank within the cell from the histogram's returning atomic
+        uint32_t rk[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            rk[k] = 0;
+            if (tid + k * T < n_round) rk[k] = atomicAdd(&s_cnt[__float_as_uint(pt[k].w) & (kBrickCells - 1)], 1u);
+        }
+        __syncthreads();
+        {  // exclusive scans over the cells: sorted position of the cell's first point, index of its first work item
+            const bool scanner = tid < (uint32_t)kBrickCells / CPT;  // wave-uniform
+            uint32_t n[CPT], it[CPT], sum_n = 0, sum_it = 0, inc_n = 0, inc_it = 0;
+            if (scanner) {
+#pragma unroll
+                for (uint32_t k = 0; k < CPT; k++) {
+                    const uint32_t c = tid * CPT + k;
+                    n[k] = s_cnt[c];
+                    const uint32_t cnt = (uint32_t)((s_info[c] >> kDepCntShift) & kDepCntMask);
+                    it[k] = n[k] ? cnt * ((n[k] + CH - 1) / CH) : 0u;
+                    sum_n += n[k];
+                    sum_it += it[k];
+                }
+                inc_n = sum_n, inc_it = sum_it;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t a = __shfl_up(inc_n, o), c2 = __shfl_up(inc_it, o);
+                    if (lane >= (uint32_t)o) inc_n += a, inc_it += c2;
+                }
+                if (lane == 63) s_wsum[0][wave] = inc_n, s_wsum[1][wave] = inc_it;
+            }
+            __syncthreads();
+            if (scanner) {
+                uint32_t pre_n = inc_n - sum_n, pre_it = inc_it - sum_it;
+                for (uint32_t w2 = 0; w2 < wave; w2++) pre_n += s_wsum[0][w2], pre_it += s_wsum[1][w2];
+#pragma unroll
+                for (uint32_t k = 0; k < CPT; k++) {
+                    const uint32_t c = tid * CPT + k;
+                    s_start[c] = pre_n;
+                    s_items[c] = pre_it;
+                    pre_n += n[k];
+                    pre_it += it[k];
+                }
+                if (tid == (uint32_t)kBrickCells / CPT - 1) s_start[kBrickCells] = pre_n, s_items[kBrickCells] = pre_it;
+            }
+        }
+        __syncthreads();
+        const uint32_t total = s_items[kBrickCells];
+        Item nxt;
+        nxt.first = nxt.p_lo = nxt.p_hi = 0;
+        nxt.e0 = nxt.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < total) locate(tid, nxt);  // entry read in flight during the scatter
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++)
+            if (tid + k * T < n_round) {
+                const uint32_t pos = s_start[__float_as_uint(pt[k].w) & (kBrickCells - 1)] + rk[k];
+                s_pts[pos] = pt[k];
+                if (COLOR) s_rgb[pos] = col[k];
+            }
+        __syncthreads();
+        if (r0 + (uint32_t)kUpd2Cap < fill) load_round(r0 + (uint32_t)kUpd2Cap);  // in flight during the items
+        for (uint32_t item = tid; item < total; item += T) {
+            const Item cur = nxt;
+            if (item + T < total) locate(item + T, nxt);
+            const F3 la = F3{cur.e0.y, cur.e0.z, cur.e0.w}, lab = F3{cur.e1.x, cur.e1.y, cur.e1.z};
+            int32_t a_n = 0, a_s = 0, a_ss = 0, a_d = 0, a_dd = 0, a_r = 0, a_g = 0, a_b = 0;
+            for (uint32_t pi = cur.p_lo; pi < cur.p_hi; pi++) {
+                const float4 q4 = s_pts[cur.first + pi];
+                float sp, distf;
+                if (!line_member(g, F3{q4.x, q4.y, q4.z}, la, lab, cur.e1.w, sp, distf)) continue;
+                const PairDelta q = pair_delta(g, sp, distf);
+                a_n++;
+                a_s += q.s;
+                a_ss += q.ss;
+                a_d += q.d;
+                a_dd += q.dd;
+                if constexpr (COLOR) {
+                    const uint32_t rgb = s_rgb[cur.first + pi];
+                    a_r += (int32_t)((rgb >> 16) & 255u);
+                    a_g += (int32_t)((rgb >> 8) & 255u);
+                    a_b += (int32_t)(rgb & 255u);
+                }
+            }
+            c_tested += cur.p_hi - cur.p_lo;
+            c_member += (uint32_t)a_n;
+            if (a_n == 0) continue;
+            const uint32_t sid = __float_as_uint(cur.e0.x);
+            uint32_t h = upd_hash(sid);
+            bool placed = false;
+            for (int probe = 0; probe < 16; probe++) {
+                const uint32_t old = atomicCAS(&keys[h], 0u, sid);
+                if (old == 0u || old == sid) {
+                    placed = true;
+                    break;
+                }
+                h = (h + 1) & (kUpdSlots - 1);
+            }
+            unsigned long long* sv = placed ? &vals[h * W] : nullptr;
+            unsigned long long* gv = &t.stats[(uint64_t)sid * kStatWords];  // table full: straight to HBM
+#define HFPF_UPD2_ADD(word, val)                                                \
+    if (placed) atomicAdd(&sv[word], (unsigned long long)(long long)(val));     \
+    else atomicAdd(&gv[word], (unsigned long long)(long long)(val))
+            HFPF_UPD2_ADD(SW_COUNT, a_n);
+            HFPF_UPD2_ADD(SW_S, a_s);
+            HFPF_UPD2_ADD(SW_SS, a_ss);
+            HFPF_UPD2_ADD(SW_D, a_d);
+            HFPF_UPD2_ADD(SW_DD, a_dd);
+            if constexpr (COLOR) {
+                HFPF_UPD2_ADD(SW_R, a_r);
+                HFPF_UPD2_ADD(SW_G, a_g);
+                HFPF_UPD2_ADD(SW_B, a_b);
+            }
+#undef HFPF_UPD2_ADD
+        }
+        __syncthreads();  // the next round rebuilds s_cnt / s_start / s_pts
+    }
+    {  // flush: 8 lanes per record
+        const uint32_t w = tid & 7u;
+        for (uint32_t sl = tid >> 3; sl < (uint32_t)kUpdSlots; sl += T / 8) {
+            const uint32_t key = keys[sl];
+            if (key != 0u && w < (uint32_t)W) atomicAdd(&t.stats[(uint64_t)key * kStatWords + w], vals[sl * W + w]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_tested += __shfl_down(c_tested, o);
+        c_member += __shfl_down(c_member, o);
+    }
+    if (lane == 0) {
+        if (c_tested) atomicAdd(&blk_ctr[0], c_tested);
+        if (c_member) atomicAdd(&blk_ctr[1], c_member);
+    }
+    __syncthreads();
     if (tid < 2 && blk_ctr[tid])
         atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
 }
