@@ -544,12 +544,15 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
 #ifndef HFPF_UPD2_CHUNK
 #define HFPF_UPD2_CHUNK 8  // points of a cell one work item takes
 #endif
+#ifndef HFPF_UPD2_WAVES
+#define HFPF_UPD2_WAVES 1
+#endif
 constexpr int kUpd2Threads = HFPF_UPD2_THREADS, kUpd2Cap = HFPF_UPD2_CAP, kUpd2Chunk = HFPF_UPD2_CHUNK;
 static_assert(kUpd2Threads == 256 || kUpd2Threads == 512 || kUpd2Threads == 1024, "k_update_cells: one or two cells per scanning thread");
 static_assert(kUpd2Cap % kUpd2Threads == 0 && kUpd2Chunk >= 1 && kUpd2Chunk <= 15, "k_update_cells: int32 item sums hold 15 contributions");
 
 template <bool COLOR>
-__global__ __launch_bounds__(kUpd2Threads) void k_update_cells(const GridParams g, const Tables t, const uint32_t n_bricks)
+__global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(const GridParams g, const Tables t, const uint32_t n_bricks)
 {
     constexpr int W = COLOR ? 8 : kStatUsed;
     constexpr uint32_t T = kUpd2Threads, NW = T / 64, CPT = T >= kBrickCells ? 1 : kBrickCells / T, PER = kUpd2Cap / T, CH = kUpd2Chunk;
@@ -684,11 +687,12 @@ __global__ __launch_bounds__(kUpd2Threads) void k_update_cells(const GridParams 
             const Item cur = nxt;
             if (item + T < total) locate(item + T, nxt);
             const F3 la = F3{cur.e0.y, cur.e0.z, cur.e0.w}, lab = F3{cur.e1.x, cur.e1.y, cur.e1.z};
+            const LineDiv dv = line_div_of(cur.e1.w);
             int32_t a_n = 0, a_s = 0, a_ss = 0, a_d = 0, a_dd = 0, a_r = 0, a_g = 0, a_b = 0;
             for (uint32_t pi = cur.p_lo; pi < cur.p_hi; pi++) {
                 const float4 q4 = s_pts[cur.first + pi];
                 float sp, distf;
-                if (!line_member(g, F3{q4.x, q4.y, q4.z}, la, lab, cur.e1.w, sp, distf)) continue;
+                if (!line_member_hoisted(g, F3{q4.x, q4.y, q4.z}, la, lab, dv, sp, distf)) continue;
                 const PairDelta q = pair_delta(g, sp, distf);
                 a_n++;
                 a_s += q.s;
@@ -1171,6 +1175,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         uint32_t sid[B];
         F3 la[B], lab[B];
         float ldd[B];
+        LineDiv ldv[B];
         int m = 0;
 #pragma unroll
         for (int k = 0; k < B; k++) {
@@ -1196,7 +1201,10 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         }
         StatDeltaT<COLOR> d[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) stat_delta_zero(d[k]);
+        for (int k = 0; k < B; k++) {
+            stat_delta_zero(d[k]);
+            ldv[k] = line_div_of(ldd[k]);  // the divisor's share of the division, once per registrant (geometry.hpp)
+        }
         if (m > 0) {
             uint32_t e = head;
             while (e) {
@@ -1207,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
                 for (int k = 0; k < B; k++) {
                     if (k < m) {
                         float sp, distf;
-                        if (line_member(g, pt, la[k], lab[k], ldd[k], sp, distf)) stat_delta_add(d[k], pair_delta(g, sp, distf), rgb);
+                        if (line_member_hoisted(g, pt, la[k], lab[k], ldv[k], sp, distf)) stat_delta_add(d[k], pair_delta(g, sp, distf), rgb);
                     }
                 }
                 e = __float_as_uint(p.w);  // one 16-byte read per hop: the link travels with the point
@@ -1725,7 +1733,10 @@ __global__ void k_probe_project(const GridParams g, const uint64_t n, const floa
     float dd, sp, distf;
     line_of(g, F3{centres[3 * i], centres[3 * i + 1], centres[3 * i + 2]}, F3{normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]}, a, ab, dd);
     const bool mem2 = line_member(g, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, a, ab, dd, sp, distf);  // the kernels' form
-    member_out[i] = (mem ? 1 : 0) | (mem2 ? 2 : 0);
+    float sp3, distf3;  // the form with the hoisted division (k_update_cells): must agree bit for bit
+    const bool mem3 = line_member_hoisted(g, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, a, ab, line_div_of(dd), sp3, distf3);
+    const bool same = mem3 == mem2 && __float_as_uint(sp3) == __float_as_uint(sp) && __float_as_uint(distf3) == __float_as_uint(distf);
+    member_out[i] = (mem ? 1 : 0) | (mem2 ? 2 : 0) | (same ? 4 : 0);
 }
 
 __global__ void k_probe_trig(const uint64_t n, const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ a_out,

@@ -460,6 +460,7 @@ class OccupancyGrid:
         # bit 0: the reference's form (f32 sqrt widened, compared with the radius); bit 1: the kernels' form (squared
         # distance against the precomputed largest passing value) -- kept for the test that the two always agree
         self.last_member_kernel_form = (member & 2) != 0
+        self.last_hoisted_division_same = (member & 4) != 0
         return proj, dist, (member & 1) != 0
 
     def probe_trig(self, y, x):

@@ -6,7 +6,8 @@
  *                       (OccupancyGrid.hpp:630-637), a5 bbox test (OccupancyGrid.hpp:639-645)
  *   hfpf_probe_normals  a11 plane fit over a 5x5x5 occupancy stencil + orientation (OccupancyGrid.hpp:282-309,356-396)
  *   hfpf_probe_project  a9 projection + cylinder membership (OccupancyGrid.hpp:40-49,261-262); member_out bit 0 = the
- *                       reference's form, bit 1 = the form the kernels use (squared distance against the largest passing value)
+ *                       reference's form, bit 1 = the form the kernels use (squared distance against the largest passing value),
+ *                       bit 2 = the form with the hoisted division gives the same membership, parameter and distance bit for bit
  *   hfpf_probe_trig     the deterministic atan2/cos/sin used inside the plane fit
  * All pointers are HOST pointers; the probes copy in, launch, copy out and synchronise.
  */

@@ -105,6 +105,29 @@ def test_projection_membership_bit_exact(oracle_mod, hfpf_mod):
     assert near.sum() > 20 and np.array_equal(member_kernel[near], member[near])
 
 
+def test_hoisted_division_is_the_plain_division_bit_for_bit(hfpf_mod):
+    """k_update_cells keeps the divisor's share of the f32 division in a register per dependant entry (geometry.hpp, LineDiv);
+    the projection parameter, the distance and the membership must come out bit-identical to the plain form, including where the
+    numerator is tiny or zero (point in the plane through the segment end) and where it leaves the window (plain division then)."""
+    rng = np.random.default_rng(21)
+    n = 1 << 20
+    c = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    nn = rng.normal(size=(n, 3))
+    nn = (nn / np.linalg.norm(nn, axis=1, keepdims=True)).astype(np.float32)
+    perp = np.cross(nn, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    rad = rng.uniform(0, 0.002, n)
+    along = rng.uniform(-0.02, 0.02, n)
+    kind = rng.integers(0, 4, n)
+    along = np.where(kind == 1, -0.015 + rng.normal(0, 1e-9, n), along)  # at the segment end a = centre - r*n: numerator ~ 0
+    p = (c.astype(np.float64) + perp * rad[:, None] + nn.astype(np.float64) * along[:, None])
+    p = np.where((kind == 2)[:, None], p * 10.0 ** rng.uniform(3, 18, (n, 1)), p).astype(np.float32)  # far outside the window
+    with hfpf_mod.OccupancyGrid(**TINY) as g:
+        g.probe_project(p, c, nn)
+        same = g.last_hoisted_division_same
+    assert same.all(), f"{(~same).sum()} of {n} inputs differ"
+
+
 def test_plane_fit_bit_exact(oracle_mod, hfpf_mod):
     rng = np.random.default_rng(13)
     n = 20000
