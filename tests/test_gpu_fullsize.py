@@ -130,6 +130,21 @@ def test_config1_full_1000_frames(hfpf_mod, synth_mod):
         assert ctr[k] == ctr2[k], k
 
 
+def test_update_forms_cell_sorted_and_per_point_give_the_same_bits(hfpf_mod, synth_mod, monkeypatch):
+    """k_update_cells (points counting-sorted by cell in LDS, several rounds of 1024 points per brick at this size; default) against
+    k_update (one lane per point, HFPF_UPDATE_FORM=points): 120 full-resolution frames in calls of 60, three clean passes --
+    rows and pair counters must be identical."""
+    sc = scenes.Scene(120, 640, 480, 0.001, clean_every=60)
+    caps = dict(max_bricks=100000, max_log_points=48 << 20, max_normals=6 << 20, max_frames=256, frame_width=640)
+    rows, ctr, _ = _stream(hfpf_mod, sc, 60, caps)
+    monkeypatch.setenv("HFPF_UPDATE_FORM", "points")
+    rows2, ctr2, _ = _stream(hfpf_mod, sc, 60, caps)
+    assert len(rows) > 500000 and ctr["dep_pairs_tested"] > 2e7
+    assert rows.tobytes() == rows2.tobytes()
+    for k in ("dep_pairs_tested", "dep_pairs_member", "replay_members", "points_buffered", "voxels_with_normal"):
+        assert ctr[k] == ctr2[k], k
+
+
 def test_config4_shared_two_cubic_metre_grid_cameras_vs_oracle(oracle_mod, hfpf_mod, synth_mod):
     """configs[3] shape: one camera per rank (distinct frame and pose seeds), shared 2 m^3 bbox @ 1 mm (1999x999x999 cells), merge
     at every clean.  3 virtual ranks on one device against the oracle fed the union of the cameras' frames in canonical
