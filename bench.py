@@ -365,7 +365,7 @@ def main():
             "host_path_frames": len(host_frames),
             "counters": {k: int(v) for k, v in ctr.items()},
             "warnings": warnings,
-            "roofline": {"bound": "hbm", "kernel": "the integrate call (bin plan + k_integrate + k_update), HIP events on the engine's stream around every call of the timed passes",
+            "roofline": {"bound": "hbm", "kernel": "the integrate call (bin plan + k_integrate + k_update_cells + k_buffer), HIP events on the engine's stream around every call of the timed passes",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBPS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_source_sha": src_sha,
