@@ -1,14 +1,14 @@
 #!/bin/bash
 # GPU box: per-kernel average durations (rocprofv3 --kernel-trace --stats) of the default bench for several builds of libhfpf.so,
 # for A/B decisions below the bench's ~1.5 % run-to-run noise.
-# usage: tools/ab_kernels.sh <name>=<path to libhfpf.so> ...        (results: gpurun_out/ab_<name>/, one summary line per kernel)
+# usage: [AB_ARGS="--workload c3"] tools/ab_kernels.sh <name>=<path to libhfpf.so> ...   (results: gpurun_out/ab_<name>/, one summary line per build)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for spec in "$@"; do
   name=${spec%%=*}; lib=${spec#*=}
   rm -rf $R/gpurun_out/ab_$name
-  HFPF_LIB=$lib timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ab_$name -o s -- python3 $R/bench.py --repeats 3 --warmup 0 --cpu-sample 0 --host-path-frames 0 > $R/gpurun_out/ab_$name.json 2> $R/gpurun_out/ab_$name.err || { echo "$name failed"; exit 1; }
+  HFPF_LIB=$lib timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ab_$name -o s -- python3 $R/bench.py --repeats 3 --warmup 0 --cpu-sample 0 --host-path-frames 0 $AB_ARGS > $R/gpurun_out/ab_$name.json 2> $R/gpurun_out/ab_$name.err || { echo "$name failed"; exit 1; }
   python3 - "$name" "$R/gpurun_out/ab_$name" <<'PY'
 import csv, glob, sys
 name, d = sys.argv[1], sys.argv[2]
