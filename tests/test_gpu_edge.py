@@ -182,3 +182,38 @@ def test_pinned_host_entry_point_matches_bounce_path(hfpf_mod, synth_mod):
         assert e.value.code == -2 and "page-locked" in str(e.value)
         g.host_free(pinned)
     assert got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("helpers", ["0", "3"])
+def test_bounce_copy_of_large_frames_with_and_without_helper_threads(hfpf_mod, synth_mod, monkeypatch, helpers):
+    """hfpf_integrate stages a frame of >= 1 MB with non-temporal stores split over the caller and HFPF_STAGE_THREADS helper
+    threads (csrc/hfpf.hip StagePool).  Full 640x480 frames (4.9 MB), more of them than the staging ring has slots, from a source
+    buffer that is NOT 16-byte aligned: the rows must equal the device-resident path's byte for byte."""
+    sc = scenes.Scene(11, 640, 480, 0.002, clean_every=4)
+    caps = dict(max_bricks=60000, max_log_points=8 << 20, max_normals=1 << 20, max_frames=64)
+    fb = sc.W * sc.H * 16
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **caps) as a:
+        dev = a.device_alloc(fb)
+        for ev in sc.schedule():
+            if ev[0] == "integrate":
+                a.device_upload(dev, sc.frame(ev[1]))
+                a.integrate_device(dev, 1, fb, sc.W * sc.H, sc.poses[ev[1]][None])
+                a.sync()
+            else:
+                a.clean()
+        ref = a.extract()
+        a.device_free(dev)
+    monkeypatch.setenv("HFPF_STAGE_THREADS", helpers)
+    backing = np.zeros(fb + 64, np.uint8)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **caps) as g:
+        for ev in sc.schedule():
+            if ev[0] == "integrate":
+                off = 4 + (ev[1] % 3) * 8  # 4, 12, 20: never a multiple of 16
+                view = backing[off:off + fb]
+                view[:] = np.frombuffer(sc.frame(ev[1]), np.uint8)
+                g.integrate(view, sc.poses[ev[1]])
+                view[:] = 0xFF  # the caller's buffer is free again when the call returns
+            else:
+                g.clean()
+        got = g.extract()
+    assert len(ref) > 20000 and got.tobytes() == ref.tobytes()
