@@ -130,13 +130,16 @@ def test_config1_full_1000_frames(hfpf_mod, synth_mod):
         assert ctr[k] == ctr2[k], k
 
 
-def test_update_forms_cell_sorted_and_per_point_give_the_same_bits(hfpf_mod, synth_mod, monkeypatch):
+@pytest.mark.parametrize("color", [False, True])
+def test_update_forms_cell_sorted_and_per_point_give_the_same_bits(hfpf_mod, synth_mod, monkeypatch, color):
     """k_update_cells (points counting-sorted by cell in LDS, several rounds of 1024 points per brick at this size; default) against
     k_update (one lane per point, HFPF_UPDATE_FORM=points): 120 full-resolution frames in calls of 60, three clean passes --
     rows and pair counters must be identical."""
     sc = scenes.Scene(120, 640, 480, 0.001, clean_every=60)
-    caps = dict(max_bricks=100000, max_log_points=48 << 20, max_normals=6 << 20, max_frames=256, frame_width=640)
+    caps = dict(max_bricks=100000, max_log_points=48 << 20, max_normals=6 << 20, max_frames=256, frame_width=640, fuse_color=color)
     rows, ctr, _ = _stream(hfpf_mod, sc, 60, caps)
+    if color:
+        assert len(np.unique(rows["rgb"])) > 1000  # the colour sums went through the sorted LDS copy (s_rgb) and the table
     monkeypatch.setenv("HFPF_UPDATE_FORM", "points")
     rows2, ctr2, _ = _stream(hfpf_mod, sc, 60, caps)
     assert len(rows) > 500000 and ctr["dep_pairs_tested"] > 2e7
