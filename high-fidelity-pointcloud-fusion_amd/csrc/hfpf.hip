@@ -541,6 +541,10 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(nv_n, 3 * (t.max_normals + 1), 0, false);
     ALLOC(stats, (t.max_normals + 1) * kStatWords, 0, false);
     t.color = (c.flags & HFPF_FLAG_FUSE_COLOR) ? 1u : 0u;
+    {
+        const char* ts = getenv("HFPF_TEST_TABLE_SKIP");
+        t.test_table_skip = (ts && ts[0] == '1') ? 1u : 0u;
+    }
     ALLOC(nv_line, 2 * (t.max_normals + 1), 0, false);
     ALLOC(nd_mask, (t.max_bricks + 1) * 8 * 2, 0, false);
     ALLOC(reg_occ, t.max_reg, 0, false);

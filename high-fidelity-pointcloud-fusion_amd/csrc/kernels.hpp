@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
             const uint32_t sid = __float_as_uint(e0.x);
             uint32_t h = upd_hash(sid);
             bool placed = false;
-            for (int probe = 0; probe < 16; probe++) {
+            for (int probe = 0; probe < ((t.test_table_skip & sid) ? 0 : 16); probe++) {
                 const uint32_t old = atomicCAS(&keys[h], 0u, sid);
                 if (old == 0u || old == sid) {
                     placed = true;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
             const uint32_t sid = __float_as_uint(cur.e0.x);
             uint32_t h = upd_hash(sid);
             bool placed = false;
-            for (int probe = 0; probe < 16; probe++) {
+            for (int probe = 0; probe < ((t.test_table_skip & sid) ? 0 : 16); probe++) {
                 const uint32_t old = atomicCAS(&keys[h], 0u, sid);
                 if (old == 0u || old == sid) {
                     placed = true;

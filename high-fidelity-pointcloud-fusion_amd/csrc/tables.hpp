@@ -113,6 +113,7 @@ struct Tables {
     float4* nv_line;  // 2 per record: (a.xyz, ab.x), (ab.y, ab.z, |ab|^2, 0): the per-voxel half of the cylinder test
     unsigned long long* stats;
     uint32_t color;   // 1 with HFPF_FLAG_FUSE_COLOR: words 5-7 of a statistics record carry the members' colour sums
+    uint32_t test_table_skip;  // tests only (HFPF_TEST_TABLE_SKIP=1): records with an odd id bypass the LDS record tables, as if they were full
     uint64_t* nd_mask;  // per brick and x-plane, 2 words: normal_found bits, has-dependants bits of the plane's 64 cells
     uint2* reg_occ;
     DepEntry* dep;

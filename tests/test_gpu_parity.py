@@ -187,3 +187,21 @@ def test_frame_width_hint_changes_nothing(oracle_mod, hfpf_mod, synth_mod, layou
     og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
     scenes.compare_rows(scenes.run(og, sc, "capture"), rows[160])
     og.close()
+
+
+def test_full_record_table_falls_back_to_device_atomics(oracle_mod, hfpf_mod, synth_mod, monkeypatch):
+    """The per-brick LDS record table of the dependant update has 512 slots; a record that finds no slot is updated with device
+    atomics instead.  A surface brick rarely sees that many records, so the fall-back is forced (HFPF_TEST_TABLE_SKIP=1: records
+    with an odd id never get a slot) for both forms of the kernel: rows must match the oracle and the ordinary run bit for bit."""
+    sc = scenes.Scene(7, 160, 120, 0.001, fx=615.0, clean_every=2)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ref = scenes.run(og, sc, "capture")
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as g:
+        plain = scenes.run(g, sc, "integrate")
+    monkeypatch.setenv("HFPF_TEST_TABLE_SKIP", "1")
+    for form in ("cells", "points"):
+        monkeypatch.setenv("HFPF_UPDATE_FORM", form)
+        with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as g:
+            got = scenes.run(g, sc, "integrate")
+        scenes.compare_rows(ref, got)
+        assert got.tobytes() == plain.tobytes(), form
