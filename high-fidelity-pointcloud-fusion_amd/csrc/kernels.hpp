@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridPar
                 m &= ~sm;
             }
         }
-        const uint32_t b = brick_acquire_wave(t, bidx, act, dir_word);
+        const uint32_t b = BIN ? brick_acquire_groups(t, bidx, act, dir_word, same_brick) : brick_acquire_wave(t, bidx, act, dir_word);
         act = act && b != 0;
         const uint32_t lcell = local_index(ix, iy, iz);
         const uint32_t slot = b * kBrickCells + lcell;

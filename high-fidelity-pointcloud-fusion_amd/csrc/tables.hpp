@@ -256,6 +256,25 @@ __device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bo
     }
     return v;
 }
+// The same when the caller already knows, per lane, the mask of the lanes that want the same brick (k_integrate groups its lanes
+// by brick anyway): the first lane of every group claims its brick in ONE pass -- the leaders of different bricks run the claim
+// side by side instead of one after the other -- and hands the id to its group.  No lane waits on another lane of its own wave
+// (leaders hold distinct bricks), only on other waves, as before.
+__device__ inline uint32_t brick_acquire_groups(const Tables& t, uint32_t bidx, bool want, uint32_t v, unsigned long long same_brick)
+{
+    const bool need = want && (v == 0 || v == kLock);
+    if (__ballot(need) == 0) return v;
+    const uint32_t lane = lane_id();
+    const uint32_t leader = want ? (uint32_t)(__ffsll((long long)same_brick) - 1) : lane;
+    // a group's lanes read the same directory word, but not necessarily the same value (another wave may publish in between):
+    // the leader claims if ANY lane of its group still needs the brick
+    const unsigned long long need_mask = __ballot(need);
+    uint32_t id = v;
+    if (want && leader == lane && (need_mask & same_brick) != 0) id = brick_acquire_single(t, bidx);
+    const uint32_t got = (uint32_t)__shfl((int)id, (int)leader);
+    return (want && (need_mask & same_brick) != 0) ? got : v;
+}
+
 __device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bool want)
 {
     uint32_t v = 0;
