@@ -262,8 +262,7 @@ __global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridPar
         if (act && !has_n && !probe && !(occ_word & bit)) {  // a stale (cached) word only sends the lane through the atomic
             unsigned long long* om = reinterpret_cast<unsigned long long*>(&t.occ_mask[plane]);
             const unsigned long long old = atomicOr(om, (unsigned long long)bit);
-            first = !(old & bit);
-            if (first) atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
+            first = !(old & bit);  // (occupancy lives in occ_mask alone; the cell's info word is not touched)
         }
         // newly occupied cells are staged in LDS (per wave) and appended to occ_list in batches: C_OCC is one address for the
         // whole chip (a same-address atomic retires every ~12 ns), so it gets one atomic per flush, not one per tile.  The
@@ -1102,7 +1101,9 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         const uint32_t b = brick_acquire_wave(t, bidx, want);
         want = want && b != 0;
         const uint32_t slot = b * kBrickCells + local_index(xx, yy, zz);
-        const bool occ = want && (t.info[slot] & kOcc);
+        uint64_t o_plane, o_bit;
+        slot_plane_bit(slot, o_plane, o_bit);
+        const bool occ = want && (t.occ_mask[o_plane] & o_bit);
         slot_[tt] = slot;
         nid_[tt] = (uint32_t)nid;
         if (occ) f_occ |= 1u << tt;
@@ -1161,11 +1162,15 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     if (j < n_touched) {
         slot = cells[j];  // touched cells in slot (brick-major) order: adjacent lanes walk chains that share cache lines
         const uint64_t info = t.info[slot];
-        if (info & kOcc) {  // only occupied cells have a buffer
-            cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-            off = info >> kDepOffShift;
-            head = t.buf_head[(uint64_t)slot * kChains + sub];
-        }
+        cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+        off = info >> kDepOffShift;
+        head = t.buf_head[(uint64_t)slot * kChains + sub];
+    }
+    {  // a cell none of whose chains holds a point (an unoccupied cell that gained its single dependant) has nothing to replay
+        uint32_t any = head;
+#pragma unroll
+        for (uint32_t o = 1; o < kChains; o <<= 1) any |= (uint32_t)__shfl_xor((int)any, (int)o);
+        if (any == 0u) cnt = 0;
     }
     uint32_t replayed = 0;
     uint32_t next = 0;  // next dependant entry to look at
@@ -1625,11 +1630,9 @@ __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const 
         const uint32_t slot = b * kBrickCells + local_index(x, y, z);
         slot_[tt] = slot;
         if (want) {
-            const unsigned int old = atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 1u);
-            if (!(old & 1u)) {
-                f_first |= 1u << tt;
-                atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (x & 7)]), 1ull << (((y & 7) << 3) | (z & 7)));
-            }
+            const unsigned long long bit = 1ull << (((y & 7) << 3) | (z & 7));
+            const unsigned long long old = atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (x & 7)]), bit);
+            if (!(old & bit)) f_first |= 1u << tt;
             if (r.first_frame < t.max_frames) {
                 atomicMin(&t.first_frame[slot], r.first_frame);
                 t.frame_vp[3 * (uint64_t)r.first_frame] = r.vx;  // same value from every exporter

@@ -39,8 +39,7 @@ constexpr int kBrickCells = 512;
 constexpr int kMaxSpin = 1 << 20;
 constexpr uint32_t kNoFrame = 0xFFFFFFFFu;
 
-// info word
-constexpr uint64_t kOcc = 1ull;
+// info word (bit 0 is unused: occupancy lives in the brick's occ_mask alone, one returning atomic per first touch)
 constexpr uint64_t kNormal = 2ull;
 constexpr int kDepCntShift = 2;
 constexpr uint64_t kDepCntMask = 0xFFFFull;
