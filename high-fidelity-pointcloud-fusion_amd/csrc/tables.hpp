@@ -7,7 +7,7 @@
 //                                    0 = untouched, kLock = being allocated, else brick id (1-based).
 //   brick b, cell (lx,ly,lz)         slot = b*512 + morton3(lx,ly,lz) (2x2x2-blocked); brick 0 is a permanent
 //                                    all-zero "null brick" so a lookup of an untouched region needs no branch.
-//   per slot:  info u64              bit0 occupied (Voxel::occupied), bit1 normal_found,
+//   per slot:  info u64              bit0 unused (Voxel::occupied lives in occ_mask), bit1 normal_found,
 //                                    bits 2..17 dependant count, bits 18..63 offset into dep[]
 //              first_frame u32       smallest frame id that touched the cell (-> VoxelInfo::viewpoint, grid.hpp:229,238)
 //              buf_head u32[4]       heads of the cell's 4 interleaved chains in the point log (VoxelInfo::buffer)
