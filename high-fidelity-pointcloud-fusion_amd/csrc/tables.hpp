@@ -238,23 +238,29 @@ __device__ inline uint32_t brick_acquire_single(const Tables& t, uint32_t bidx)
 // stale 0 only sends the lane through the atomic path.
 __device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bool want, uint32_t v)
 {
-    bool need = want && (v == 0 || v == kLock);
+    const bool need = want && (v == 0 || v == kLock);
     unsigned long long m = __ballot(need);
+    if (m == 0) return v;
+    // The lanes that need a brick are grouped by brick with registers and scalar lane reads only; then the first lane of every
+    // group claims its brick, all of them side by side (a claim is a chain of three memory round trips: one after the other
+    // they cost a wave ~3 us per new brick).  No lane waits on another lane of its own wave: the leaders hold distinct bricks.
     const uint32_t lane = lane_id();
+    unsigned long long grp = 0;
     while (m) {
         const int leader = __ffsll((long long)m) - 1;
-        const uint32_t lb = __shfl(bidx, leader);
-        uint32_t id = 0;
-        if (lane == (uint32_t)leader) id = brick_acquire_single(t, lb);
-        id = __shfl(id, leader);
-        if (need && bidx == lb) {
-            v = id;
-            need = false;
-        }
-        m = __ballot(need);
+        const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bidx, leader);
+        const bool same = need && bidx == lb;
+        const unsigned long long sm = __ballot(same);
+        if (same) grp = sm;
+        m &= ~sm;
     }
-    return v;
+    const uint32_t leader_lane = need ? (uint32_t)(__ffsll((long long)grp) - 1) : lane;
+    uint32_t id = v;
+    if (need && leader_lane == lane) id = brick_acquire_single(t, bidx);
+    const uint32_t got = (uint32_t)__shfl((int)id, (int)leader_lane);
+    return need ? got : v;
 }
+
 // The same when the caller already knows, per lane, the mask of the lanes that want the same brick (k_integrate groups its lanes
 // by brick anyway): the first lane of every group claims its brick in ONE pass -- the leaders of different bricks run the claim
 // side by side instead of one after the other -- and hands the id to its group.  No lane waits on another lane of its own wave
