@@ -992,7 +992,7 @@ int clean_locked(hfpf_handle* h)
             h->n_linked[r] = n_r;
         }
         // entries appended by k_buffer arrive chained; only k_integrate's direct form leaves marked entries behind
-        if (max_new && h->h_ctr[C_BUFFERED] != h->direct_linked) {
+        if (max_new && !h->binned && h->h_ctr[C_BUFFERED] != h->direct_linked) {  // (the binned form chains its few direct appends itself)
             hipLaunchKernelGGL(k_link_log, dim3(blocks_for(max_new, 256), kLogRegions), dim3(256), 0, s, t, lr);
             HIPCHK(h, hipGetLastError());
         }

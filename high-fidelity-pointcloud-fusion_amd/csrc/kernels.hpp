@@ -44,6 +44,7 @@ struct FrameLayout {
 #define HFPF_REPLAY_B 3  // registrants per chain walk held in registers by k_replay
 #endif
 constexpr int kLogRegions = 64;
+constexpr uint32_t kLogChains = 4;  // interleaved chains per cell (= kChains below: entry e joins chain e mod 4 of its cell)
 constexpr uint32_t kLogUnlinked = 0x80000000u;  // log entry .w = slot | this bit until the entry is chained (then: index of the next entry)
 #ifndef HFPF_REG_TILES
 #define HFPF_REG_TILES 8  // 256-voxel tiles one workgroup of k_register takes per list reservation
@@ -328,7 +329,12 @@ __global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridPar
         if (buf) {
             if (li < t.log_region_cap) {
                 const uint64_t e = log_base + li + 1;
-                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(slot | kLogUnlinked));  // .w: marked slot until k_link_log chains it
+                // Binned form: this is the rare lane whose bin region was full, so it chains its entry right here (one returning
+                // atomic) and no pass over the log is needed afterwards.  Direct form (every point comes this way): .w carries the
+                // marked slot until k_link_log chains the entries of the epoch in one go.
+                uint32_t link = slot | kLogUnlinked;
+                if (BIN) link = atomicExch(&t.buf_head[(uint64_t)slot * kLogChains + ((uint32_t)e & (kLogChains - 1))], (uint32_t)e);
+                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(link));
                 if (COLOR) t.log_rgb[e] = rgb;
             } else {
                 atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
 // returning device atomic per buffered point in a separate pass over the log (k_link_log's atomicExch, ~1.2 ms for the
 // first epoch's 39 M entries) and keeps a cell's entries of one launch within a few KB of each other for the replay's
 // chain walks.
-constexpr uint32_t kChains = 4;       // interleaved chains per cell: k_replay walks them with 4 lanes in parallel
+constexpr uint32_t kChains = kLogChains;  // interleaved chains per cell: k_replay walks them with 4 lanes in parallel
 constexpr uint32_t kBufLdsMin = 256;  // runs at least this long chain in LDS
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_buffer(const GridParams g, const Tables t, const uint32_t n_bricks)
