@@ -230,6 +230,7 @@ struct hfpf_handle {
     void* rccl_lib = nullptr;
     void* comm = nullptr;  // ncclComm_t
     uint64_t occ_exported = 0;  // occ_list entries already exchanged
+    uint64_t ex_cap_records = 0;  // records the exchange buffers hold per rank; kept EQUAL on every rank (same initial value, same growth rule)
     DevBuf ex_send, ex_recv, ex_counts, stats_total;
     unsigned long long* h_counts = nullptr;  // pinned, world entries
 
@@ -909,44 +910,80 @@ int import_gathered_locked(hfpf_handle* h, const void* dev_buffer, uint64_t slic
     return HFPF_OK;
 }
 
-// RCCL exchange at the head of a clean pass: all-gather the counts, then the (padded) record lists.  A rank that failed
-// locally still takes part in the count gather and flags it there, so that every rank leaves the collective sequence at the
-// same point instead of blocking in a collective its peer never enters.
-int dist_exchange_locked(hfpf_handle* h)
+// Failure consensus in front of a data collective: every rank contributes ONE status word (a payload below 2^63, bit 63 = "this
+// rank has failed") to an all-gather that it enters whatever happened to it locally -- the status gather itself needs nothing but
+// the (world+1)-word buffer allocated by hfpf_dist_init.  Afterwards every rank knows whether any rank failed and all of them
+// leave the collective sequence at the same point: the failed rank with its own error, the others with HFPF_ERR_DIST.  Without
+// it a rank that returns early (capacity overflow, poisoned handle, failed allocation) leaves its peers blocked in the next
+// ncclAllGather / ncclAllReduce for ever.  payloads_out (world entries, may be null) receives every rank's payload.
+int dist_status_gather_locked(hfpf_handle* h, int local_rc, uint64_t payload, const char* where, unsigned long long* payloads_out)
 {
     constexpr unsigned long long kFailBit = 1ull << 63;
-    uint64_t n_mine = 0;
-    int rc = epoch_export_locked(h, &n_mine, 0);
-    const int local_rc = rc;
-    if (local_rc) n_mine = 0;
-    if ((rc = scratch(h, h->ex_counts, (size_t)(h->world + 1) * 8))) return rc;
+    const std::string local_err = h->err;  // keep the text of the local failure: the calls below may overwrite it
     unsigned long long* d_counts = (unsigned long long*)h->ex_counts.p;
-    h->h_counts[h->world] = n_mine | (local_rc ? kFailBit : 0ull);
+    if (!d_counts || !h->h_counts) return fail(h, HFPF_ERR_DIST, "%s: no status buffer (hfpf_dist_init did not complete)", where);
+    h->h_counts[h->world] = (payload & ~kFailBit) | (local_rc ? kFailBit : 0ull);
     HIPCHK(h, hipMemcpyAsync(d_counts + h->world, h->h_counts + h->world, 8, hipMemcpyHostToDevice, h->stream));
     NCCLCHK(h, g_rccl.AllGather(d_counts + h->world, d_counts, 1, ncclUint64_, (ncclComm_t_)h->comm, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_counts, d_counts, (size_t)h->world * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    uint64_t maxc = 0;
     int failed_rank = -1;
     for (int r = 0; r < h->world; r++) {
-        if (h->h_counts[r] & kFailBit) failed_rank = r;
+        if ((h->h_counts[r] & kFailBit) && failed_rank < 0) failed_rank = r;
         h->h_counts[r] &= ~kFailBit;
-        maxc = std::max<uint64_t>(maxc, h->h_counts[r]);
+        if (payloads_out) payloads_out[r] = h->h_counts[r];
     }
-    if (local_rc) return local_rc;  // h->err already says why
-    if (failed_rank >= 0) return fail(h, HFPF_ERR_DIST, "rank %d failed before the epoch exchange; this pass is abandoned on every rank", failed_rank);
-    if (maxc == 0) return HFPF_OK;
-    // the send buffer must hold maxc records (padding is never read by the importers)
-    if (h->ex_send.bytes < maxc * sizeof(EpochRec)) {
+    if (local_rc) {
+        h->err = local_err;
+        return local_rc;
+    }
+    if (failed_rank >= 0) return fail(h, HFPF_ERR_DIST, "rank %d failed before the %s; the call is abandoned on every rank", failed_rank, where);
+    return HFPF_OK;
+}
+
+// Exchange buffers for `records` records per rank.  The send buffer keeps its first `keep` records.
+int grow_exchange_buffers_locked(hfpf_handle* h, uint64_t records, uint64_t keep)
+{
+    int rc;
+    if (h->ex_send.bytes < records * sizeof(EpochRec)) {
         DevBuf bigger;
-        if ((rc = scratch(h, bigger, maxc * sizeof(EpochRec)))) return rc;
-        if (n_mine) HIPCHK(h, hipMemcpyAsync(bigger.p, h->ex_send.p, n_mine * sizeof(EpochRec), hipMemcpyDeviceToDevice, h->stream));
+        if ((rc = scratch(h, bigger, records * sizeof(EpochRec)))) return rc;
+        if (keep) HIPCHK(h, hipMemcpyAsync(bigger.p, h->ex_send.p, keep * sizeof(EpochRec), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipFree(h->ex_send.p));
-        h->device_bytes -= h->ex_send.bytes;
+        if (h->ex_send.p) {
+            HIPCHK(h, hipFree(h->ex_send.p));
+            h->device_bytes -= h->ex_send.bytes;
+        }
         h->ex_send = bigger;
     }
-    if ((rc = scratch(h, h->ex_recv, (size_t)h->world * maxc * sizeof(EpochRec)))) return rc;
+    return scratch(h, h->ex_recv, (size_t)h->world * records * sizeof(EpochRec));
+}
+
+// RCCL exchange at the head of a clean pass: status gather (with the per-rank record counts as payload), then the all-gather of
+// the padded record lists.  pre_rc != 0: this rank failed before the call (poisoned handle); it still takes part in the status
+// gather so that its peers return an error instead of waiting for it.  Nothing that can fail sits between two collectives
+// without a status gather behind it: the buffers hold ex_cap_records per rank -- the same number on every rank, because it
+// starts from the same configuration and grows by the same rule from the same gathered maximum -- so "must grow" is the same
+// decision everywhere, and the ranks that grow agree on the outcome before the record gather.
+int dist_exchange_locked(hfpf_handle* h, int pre_rc)
+{
+    uint64_t n_mine = 0;
+    int local_rc = pre_rc;
+    if (!local_rc) local_rc = epoch_export_locked(h, &n_mine, h->ex_cap_records);
+    if (local_rc) n_mine = 0;
+    int rc = dist_status_gather_locked(h, local_rc, n_mine, "epoch exchange", nullptr);
+    if (rc) return rc;
+    uint64_t maxc = 0;
+    for (int r = 0; r < h->world; r++) maxc = std::max<uint64_t>(maxc, h->h_counts[r]);
+    if (maxc == 0) return HFPF_OK;
+    if (maxc > h->ex_cap_records) {
+        const uint64_t new_cap = maxc + maxc / 4;
+        const int grc = grow_exchange_buffers_locked(h, new_cap, n_mine);
+        std::vector<unsigned long long> counts(h->h_counts, h->h_counts + h->world);  // the second gather reuses h_counts
+        if ((rc = dist_status_gather_locked(h, grc, new_cap, "growth of the exchange buffers", nullptr))) return rc;
+        std::copy(counts.begin(), counts.end(), h->h_counts);
+        h->ex_cap_records = new_cap;
+    }
     NCCLCHK(h, g_rccl.AllGather(h->ex_send.p, h->ex_recv.p, maxc * sizeof(EpochRec), ncclChar_, (ncclComm_t_)h->comm, h->stream));
     return import_gathered_locked(h, h->ex_recv.p, maxc * sizeof(EpochRec), h->world, h->rank, h->h_counts);
 }
@@ -965,12 +1002,14 @@ void launch_gate(hfpf_handle* h, const uint32_t* cells_a, uint64_t n_a, const ui
 // One clean pass.  Two host read-backs: at the start (what the integrate launches since the last pass produced) and after the
 // dependant-table update (how many cells to replay, overflow bits).  Everything between them is sized from upper bounds on the
 // host and reads its exact counts from the device counters.
-int clean_locked(hfpf_handle* h)
+int clean_locked(hfpf_handle* h, int pre_rc)
 {
     Tables& t = h->t;
     hipStream_t s = h->stream;
     int rc;
-    if (h->dist_on && (rc = dist_exchange_locked(h))) return rc;  // collective: every rank cleans at the same schedule point
+    // collective: every rank cleans at the same schedule point; a rank that is already unusable (pre_rc) still says so to its peers
+    if (h->dist_on && (rc = dist_exchange_locked(h, pre_rc))) return rc;
+    if (pre_rc) return pre_rc;
     if ((rc = read_counters(h))) return rc;
     if ((rc = check_device_errors(h))) return rc;
     const uint64_t n_occ = std::min<uint64_t>(h->h_ctr[C_OCC], t.max_occ);
@@ -1378,8 +1417,9 @@ int hfpf_clean(hfpf_handle* h)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (int rc0 = check_usable(h)) return rc0;
-    if (!h->timing) return poison_on_error(h, clean_locked(h));
+    const int pre = check_usable(h);
+    if (pre && !h->dist_on) return pre;
+    if (!h->timing || pre) return poison_on_error(h, clean_locked(h, pre));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto get = [&](hipEvent_t& e) -> hipError_t {
         if (!h->ev_free.empty()) {
@@ -1392,7 +1432,7 @@ int hfpf_clean(hfpf_handle* h)
     HIPCHK(h, get(e0));
     HIPCHK(h, get(e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));  // after every queued integrate: measures the clean pass alone
-    const int rc = poison_on_error(h, clean_locked(h));
+    const int rc = poison_on_error(h, clean_locked(h, 0));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     h->ev_pending_clean.emplace_back(e0, e1);
     return rc;
@@ -1451,15 +1491,25 @@ int hfpf_extract_filtered(hfpf_handle* h, const hfpf_extract_opts* opts, hfpf_ro
     *n_rows = 0;
     Tables& t = h->t;
     int rc = check_usable(h);
-    if (rc) return rc;
-    if ((rc = read_counters(h))) return rc;
-    if ((rc = check_device_errors(h))) return poison_on_error(h, rc);
+    if (!rc) rc = read_counters(h);
+    if (!rc) rc = poison_on_error(h, check_device_errors(h));
+    if (rc && !h->dist_on) return rc;
     const unsigned long long* stats = t.stats;
     if (h->dist_on) {
         // Sum the ranks' private partial records (exact integer adds) into scratch; the partials stay intact.
-        // Normal records are replicated, so every rank holds the same n and the same record ids.
-        const uint64_t words = (h->h_ctr[C_NORMALS] + 1) * kStatWords;
-        if ((rc = scratch(h, h->stats_total, words * 8))) return rc;
+        // Normal records are replicated, so every rank holds the same n and the same record ids -- checked: the count travels as
+        // the payload of the status gather that makes every rank agree to enter the all-reduce (or to leave together).
+        // The whole table is reduced, (n + 1) x 64 bytes = 125 MB at 2 M voxels: one collective per extract, a few ms over xGMI
+        // against an extract that sorts and downloads the same records; a list of touched records would need a second collective.
+        const uint64_t n_mine = h->h_ctr[C_NORMALS];
+        const uint64_t words = (n_mine + 1) * kStatWords;
+        if (!rc) rc = scratch(h, h->stats_total, words * 8);
+        std::vector<unsigned long long> n_of(h->world, 0ull);
+        if ((rc = dist_status_gather_locked(h, rc, n_mine, "statistics all-reduce of extract", n_of.data()))) return rc;
+        for (int r = 0; r < h->world; r++)  // every rank sees the same payloads, so all of them take this exit or none does
+            if (n_of[r] != n_of[0])
+                return fail(h, HFPF_ERR_DIST, "rank %d holds %llu normal records, rank 0 %llu: the ranks did not run the same clean schedule", r,
+                            (unsigned long long)n_of[r], (unsigned long long)n_of[0]);
         NCCLCHK(h, g_rccl.AllReduce(t.stats, h->stats_total.p, words, ncclUint64_, ncclSum_, (ncclComm_t_)h->comm, h->stream));
         stats = (const unsigned long long*)h->stats_total.p;
     }
@@ -1485,7 +1535,9 @@ int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words,
     if (!h || !dev_words || !n_words) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    int rc = read_counters(h);
+    int rc = check_usable(h);
+    if (!rc) rc = read_counters(h);
+    if (!rc) rc = poison_on_error(h, check_device_errors(h));
     if (rc) return rc;
     *dev_words = h->t.stats;
     *n_words = (h->h_ctr[C_NORMALS] + 1) * kStatWords;
@@ -1500,7 +1552,8 @@ int hfpf_epoch_export(hfpf_handle* h, const void** dev_records, uint64_t* n_reco
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     uint64_t n = 0;
-    int rc = epoch_export_locked(h, &n, 0);
+    int rc = check_usable(h);
+    if (!rc) rc = epoch_export_locked(h, &n, 0);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *dev_records = h->ex_send.p;
@@ -1579,6 +1632,7 @@ int hfpf_dist_init(hfpf_handle* h, int rank, int world, const void* id128)
         if ((rc = scratch(h, h->ex_counts, (size_t)(world + 1) * 8)) || (rc = scratch(h, h->ex_send, recs * sizeof(EpochRec))) ||
             (rc = scratch(h, h->ex_recv, (size_t)world * recs * sizeof(EpochRec))))
             return rc;
+        h->ex_cap_records = recs;
     }
     h->dist_on = true;
     return HFPF_OK;

@@ -540,6 +540,17 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
 // points come from LDS (lanes of one cell read the same address), the contributions are summed in registers (int32: one is below
 // 2^27, stats.hpp) and the item ends with ONE hash insert + five LDS atomics.  Same LDS record table and flush as above; the
 // sums are integers, so the result is bit-identical whatever the order.
+//
+// Thread t owns cell t of the brick for the whole launch (its dependant count and list offset stay in registers).  A round:
+//   1. histogram of the round's points by cell with returning LDS atomics (= rank of the point inside its cell)      | barrier
+//   2. owner threads: exclusive scans over the cells (first sorted position, first work item) -- wave scan             | barrier
+//   3. owner threads: per-cell record (list offset, first position, points) and one 32-bit DESCRIPTOR per work item
+//      (cell, chunk, entry) written into LDS in item order                                                             | barrier
+//   4. points scattered into LDS in cell order; the first item's dependant entry is already in flight                  | barrier
+//   5. items: descriptor -> cell record -> entry (global, read one item ahead) -> pair loop over the run -> table insert
+// An item finds its work with two dependent LDS reads (round 2: a 9-step binary search over the item prefix sums, i.e. nine
+// dependent LDS reads per item, ~1000 cycles of latency in front of every entry read).  Items beyond the descriptor array
+// (kUpd2Desc per round) and entries past 32766 keep the search.
 #ifndef HFPF_UPD2_THREADS
 #define HFPF_UPD2_THREADS 512
 #endif
@@ -552,9 +563,17 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
 #ifndef HFPF_UPD2_WAVES
 #define HFPF_UPD2_WAVES 1
 #endif
-constexpr int kUpd2Threads = HFPF_UPD2_THREADS, kUpd2Cap = HFPF_UPD2_CAP, kUpd2Chunk = HFPF_UPD2_CHUNK;
+#ifndef HFPF_UPD2_DESC
+#define HFPF_UPD2_DESC 1024  // work items of a round that get a descriptor (4 bytes each)
+#endif
+#ifndef HFPF_UPD2_ABL
+#define HFPF_UPD2_ABL 0  // TIMING-ONLY ablations (the results are wrong): 1 no table insert, 2 no pair loop, 3 no items, 4 loads only
+#endif
+constexpr int kUpd2Threads = HFPF_UPD2_THREADS, kUpd2Cap = HFPF_UPD2_CAP, kUpd2Chunk = HFPF_UPD2_CHUNK, kUpd2Desc = HFPF_UPD2_DESC;
 static_assert(kUpd2Threads == 256 || kUpd2Threads == 512 || kUpd2Threads == 1024, "k_update_cells: one or two cells per scanning thread");
 static_assert(kUpd2Cap % kUpd2Threads == 0 && kUpd2Chunk >= 1 && kUpd2Chunk <= 15, "k_update_cells: int32 item sums hold 15 contributions");
+static_assert(kUpd2Cap <= 4095 && (kUpd2Cap + kUpd2Chunk - 1) / kUpd2Chunk <= 256, "k_update_cells: cell record holds 12-bit positions, descriptor 8-bit chunks");
+constexpr uint32_t kUpd2NoDesc = ~0u;
 
 template <bool COLOR>
 __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(const GridParams g, const Tables t, const uint32_t n_bricks)
@@ -563,10 +582,10 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
     constexpr uint32_t T = kUpd2Threads, NW = T / 64, CPT = T >= kBrickCells ? 1 : kBrickCells / T, PER = kUpd2Cap / T, CH = kUpd2Chunk;
     __shared__ float4 s_pts[kUpd2Cap];
     __shared__ uint32_t s_rgb[COLOR ? kUpd2Cap : 1];
-    __shared__ uint64_t s_info[kBrickCells];
     __shared__ uint32_t s_cnt[kBrickCells];
-    __shared__ uint32_t s_start[kBrickCells + 1];  // first sorted position of each cell's points
-    __shared__ uint32_t s_items[kBrickCells + 1];  // first work item of each cell
+    __shared__ uint64_t s_pack[kBrickCells];       // per cell and round: dependant-list offset (32) | first sorted position (12) | points (12)
+    __shared__ uint32_t s_items[kBrickCells + 1];  // first work item of each cell (only the search path and the total read it)
+    __shared__ uint32_t s_desc[kUpd2Desc];         // per work item: cell (9) | chunk (8) | entry (15)
     __shared__ uint32_t s_wsum[2][NW];
     __shared__ uint32_t keys[kUpdSlots];
     __shared__ unsigned long long vals[kUpdSlots * W];
@@ -579,14 +598,22 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t first_a = t.bin_off[2 * b], first_b = t.bin_off[2 * b + 1];
     auto entry = [&](uint32_t i) -> uint64_t { return i < fill_a ? first_a + i : first_b + (i - fill_a); };
-    for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += T) s_info[i] = t.info[(uint64_t)b * kBrickCells + i];
+    const bool scanner = tid < (uint32_t)kBrickCells / CPT;  // wave-uniform: the threads that own cells
+    uint32_t own_cnt[CPT], own_off[CPT];
+#pragma unroll
+    for (uint32_t k = 0; k < CPT; k++) {
+        const uint64_t info = scanner ? t.info[(uint64_t)b * kBrickCells + tid * CPT + k] : 0ull;
+        own_cnt[k] = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+        own_off[k] = (uint32_t)(info >> kDepOffShift);  // dep[] stays below 2^32 entries (host-checked)
+    }
+    for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += T) s_cnt[i] = 0;
     for (uint32_t i = tid; i < (uint32_t)kUpdSlots; i += T) keys[i] = 0;
     for (uint32_t i = tid; i < (uint32_t)(kUpdSlots * W); i += T) vals[i] = 0;
     if (tid < 2) blk_ctr[tid] = 0;
     const float4* __restrict__ dep4 = reinterpret_cast<const float4*>(t.dep);
     uint32_t c_tested = 0, c_member = 0;
     // Software pipeline: the points of round r+1 are read from the bin while round r's items are worked, and an item's dependant
-    // entry is read one item ahead (the first one of a round right after the scan, ahead of the scatter).
+    // entry is read one item ahead (the first one of a round ahead of the scatter).
     float4 pt[PER];
     uint32_t col[PER];
     auto load_round = [&](uint32_t r0) {
@@ -606,30 +633,50 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
         float4 e0, e1;
     };
     auto locate = [&](uint32_t item, Item& it) {  // work item -> (cell, entry, run of points) + the entry's two 16-byte halves
-        uint32_t lo = 0, hi = kBrickCells;  // s_items[lo] <= item < s_items[hi]
-#pragma unroll
-        for (int st = 0; st < 9; st++) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_items[mid] <= item) lo = mid;
-            else hi = mid;
+        uint32_t d = kUpd2NoDesc;
+        if (item < (uint32_t)kUpd2Desc) d = s_desc[item];
+        uint32_t c, j, ch;
+        if (d != kUpd2NoDesc) {
+            c = d & (kBrickCells - 1);
+            ch = (d >> 9) & 255u;
+            j = d >> 17;
+        } else {  // no descriptor: search the item prefix sums (s_items[lo] <= item < s_items[hi])
+            uint32_t lo = 0, hi = kBrickCells;
+#pragma unroll 1
+            for (int st = 0; st < 9; st++) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_items[mid] <= item) lo = mid;
+                else hi = mid;
+            }
+            c = lo;
+            const uint32_t local = item - s_items[lo];
+            const uint32_t chunks = ((uint32_t)((s_pack[lo] >> 44) & 0xFFFu) + CH - 1) / CH;
+            j = local / chunks;
+            ch = local - j * chunks;
         }
-        const uint32_t local = item - s_items[lo];
-        it.first = s_start[lo];
-        const uint32_t n_c = s_start[lo + 1] - it.first;
-        const uint32_t chunks = (n_c + CH - 1) / CH;
-        const uint32_t j = local / chunks, ch = local - j * chunks;
-        const uint64_t off = s_info[lo] >> kDepOffShift;
-        it.e0 = dep4[2 * (off + j)];
-        it.e1 = dep4[2 * (off + j) + 1];
+        const uint64_t pk = s_pack[c];
+        const uint32_t n_c = (uint32_t)((pk >> 44) & 0xFFFu);
+        it.first = (uint32_t)((pk >> 32) & 0xFFFu);
+        const uint64_t e = (uint64_t)(uint32_t)pk + j;
+        it.e0 = dep4[2 * e];
+        it.e1 = dep4[2 * e + 1];
         it.p_lo = ch * CH;
         it.p_hi = min(n_c, it.p_lo + CH);
     };
     load_round(0);
+    __syncthreads();
+#if HFPF_UPD2_ABL == 4
+    {
+        uint32_t keep = own_cnt[0] ^ own_off[0];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) keep ^= __float_as_uint(pt[k].x) ^ __float_as_uint(pt[k].w);
+        if (keep == 0x12345u) atomicAdd(&blk_ctr[0], 1u);
+        return;
+    }
+#endif
     for (uint32_t r0 = 0; r0 < fill; r0 += (uint32_t)kUpd2Cap) {  // block-uniform trip count
         const uint32_t n_round = min((uint32_t)kUpd2Cap, fill - r0);
-        for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += T) s_cnt[i] = 0;
-        __syncthreads();
-        // rank within the cell from the histogram's returning atomic
+        // 1. rank within the cell from the histogram's returning atomic
         uint32_t rk[PER];
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++) {
@@ -637,67 +684,82 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
             if (tid + k * T < n_round) rk[k] = atomicAdd(&s_cnt[__float_as_uint(pt[k].w) & (kBrickCells - 1)], 1u);
         }
         __syncthreads();
-        {  // exclusive scans over the cells: sorted position of the cell's first point, index of its first work item
-            const bool scanner = tid < (uint32_t)kBrickCells / CPT;  // wave-uniform
-            uint32_t n[CPT], it[CPT], sum_n = 0, sum_it = 0, inc_n = 0, inc_it = 0;
-            if (scanner) {
+        // 2. exclusive scans over the cells: sorted position of the cell's first point, index of its first work item
+        uint32_t n[CPT], it[CPT], sum_n = 0, sum_it = 0, inc_n = 0, inc_it = 0;
+        if (scanner) {
 #pragma unroll
-                for (uint32_t k = 0; k < CPT; k++) {
-                    const uint32_t c = tid * CPT + k;
-                    n[k] = s_cnt[c];
-                    const uint32_t cnt = (uint32_t)((s_info[c] >> kDepCntShift) & kDepCntMask);
-                    it[k] = n[k] ? cnt * ((n[k] + CH - 1) / CH) : 0u;
-                    sum_n += n[k];
-                    sum_it += it[k];
-                }
-                inc_n = sum_n, inc_it = sum_it;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t a = __shfl_up(inc_n, o), c2 = __shfl_up(inc_it, o);
-                    if (lane >= (uint32_t)o) inc_n += a, inc_it += c2;
-                }
-                if (lane == 63) s_wsum[0][wave] = inc_n, s_wsum[1][wave] = inc_it;
+            for (uint32_t k = 0; k < CPT; k++) {
+                const uint32_t c = tid * CPT + k;
+                n[k] = s_cnt[c];
+                s_cnt[c] = 0;  // for the next round's histogram (three barriers away)
+                it[k] = n[k] ? own_cnt[k] * ((n[k] + CH - 1) / CH) : 0u;
+                sum_n += n[k];
+                sum_it += it[k];
             }
-            __syncthreads();
-            if (scanner) {
-                uint32_t pre_n = inc_n - sum_n, pre_it = inc_it - sum_it;
-                for (uint32_t w2 = 0; w2 < wave; w2++) pre_n += s_wsum[0][w2], pre_it += s_wsum[1][w2];
+            inc_n = sum_n, inc_it = sum_it;
 #pragma unroll
-                for (uint32_t k = 0; k < CPT; k++) {
-                    const uint32_t c = tid * CPT + k;
-                    s_start[c] = pre_n;
-                    s_items[c] = pre_it;
-                    pre_n += n[k];
-                    pre_it += it[k];
-                }
-                if (tid == (uint32_t)kBrickCells / CPT - 1) s_start[kBrickCells] = pre_n, s_items[kBrickCells] = pre_it;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t a = __shfl_up(inc_n, o), c2 = __shfl_up(inc_it, o);
+                if (lane >= (uint32_t)o) inc_n += a, inc_it += c2;
             }
+            if (lane == 63) s_wsum[0][wave] = inc_n, s_wsum[1][wave] = inc_it;
         }
         __syncthreads();
-        const uint32_t total = s_items[kBrickCells];
+        // 3. cell records and item descriptors
+        if (scanner) {
+            uint32_t pre_n = inc_n - sum_n, pre_it = inc_it - sum_it;
+            for (uint32_t w2 = 0; w2 < wave; w2++) pre_n += s_wsum[0][w2], pre_it += s_wsum[1][w2];
+#pragma unroll
+            for (uint32_t k = 0; k < CPT; k++) {
+                const uint32_t c = tid * CPT + k;
+                s_pack[c] = (uint64_t)own_off[k] | ((uint64_t)pre_n << 32) | ((uint64_t)n[k] << 44);
+                s_items[c] = pre_it;
+                if (it[k]) {
+                    const uint32_t chunks = (n[k] + CH - 1) / CH;
+                    uint32_t idx = pre_it;
+                    for (uint32_t j = 0; j < own_cnt[k] && idx < (uint32_t)kUpd2Desc; j++)
+                        for (uint32_t ch = 0; ch < chunks && idx < (uint32_t)kUpd2Desc; ch++, idx++)
+                            s_desc[idx] = j < 32767u ? (c | (ch << 9) | (j << 17)) : kUpd2NoDesc;
+                }
+                pre_n += n[k];
+                pre_it += it[k];
+            }
+            if (tid == (uint32_t)kBrickCells / CPT - 1) s_items[kBrickCells] = pre_it;
+        }
+        __syncthreads();
+        const uint32_t total = HFPF_UPD2_ABL == 3 ? 0u : s_items[kBrickCells];
         Item nxt;
         nxt.first = nxt.p_lo = nxt.p_hi = 0;
         nxt.e0 = nxt.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < total) locate(tid, nxt);  // entry read in flight during the scatter
+        // 4. scatter into cell order
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++)
             if (tid + k * T < n_round) {
-                const uint32_t pos = s_start[__float_as_uint(pt[k].w) & (kBrickCells - 1)] + rk[k];
+                const uint32_t pos = (uint32_t)((s_pack[__float_as_uint(pt[k].w) & (kBrickCells - 1)] >> 32) & 0xFFFu) + rk[k];
                 s_pts[pos] = pt[k];
                 if (COLOR) s_rgb[pos] = col[k];
             }
         __syncthreads();
         if (r0 + (uint32_t)kUpd2Cap < fill) load_round(r0 + (uint32_t)kUpd2Cap);  // in flight during the items
+        // 5. items.  No barrier behind them: the next round's histogram only touches s_cnt, and its first barrier keeps every
+        // writer of s_pack / s_desc / s_pts behind the last reader of this round.
         for (uint32_t item = tid; item < total; item += T) {
             const Item cur = nxt;
             if (item + T < total) locate(item + T, nxt);
             const F3 la = F3{cur.e0.y, cur.e0.z, cur.e0.w}, lab = F3{cur.e1.x, cur.e1.y, cur.e1.z};
             const LineDiv dv = line_div_of(cur.e1.w);
             int32_t a_n = 0, a_s = 0, a_ss = 0, a_d = 0, a_dd = 0, a_r = 0, a_g = 0, a_b = 0;
+#if HFPF_UPD2_ABL == 2
+            c_member += (__float_as_uint(cur.e0.x) ^ __float_as_uint(cur.e1.w) ^ __float_as_uint(la.x) ^ __float_as_uint(lab.x) ^ __float_as_uint(dv.r)) & 1u;
+#else
+            F3 qn = F3{0.f, 0.f, 0.f};  // the next point of the run is read while this one is tested
+            if (cur.p_lo < cur.p_hi) qn = *reinterpret_cast<const F3*>(&s_pts[cur.first + cur.p_lo]);
             for (uint32_t pi = cur.p_lo; pi < cur.p_hi; pi++) {
-                const float4 q4 = s_pts[cur.first + pi];
+                const F3 q3 = qn;
+                if (pi + 1 < cur.p_hi) qn = *reinterpret_cast<const F3*>(&s_pts[cur.first + pi + 1]);
                 float sp, distf;
-                if (!line_member_hoisted(g, F3{q4.x, q4.y, q4.z}, la, lab, dv, sp, distf)) continue;
+                if (!line_member_hoisted(g, q3, la, lab, dv, sp, distf)) continue;
                 const PairDelta q = pair_delta(g, sp, distf);
                 a_n++;
                 a_s += q.s;
@@ -711,8 +773,13 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
                     a_b += (int32_t)(rgb & 255u);
                 }
             }
+#endif
             c_tested += cur.p_hi - cur.p_lo;
             c_member += (uint32_t)a_n;
+#if HFPF_UPD2_ABL == 1
+            c_member += (uint32_t)(a_s ^ a_ss ^ a_d ^ a_dd ^ a_r ^ a_g ^ a_b) & 1u;
+            continue;
+#endif
             if (a_n == 0) continue;
             const uint32_t sid = __float_as_uint(cur.e0.x);
             uint32_t h = upd_hash(sid);
@@ -742,8 +809,8 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
             }
 #undef HFPF_UPD2_ADD
         }
-        __syncthreads();  // the next round rebuilds s_cnt / s_start / s_pts
     }
+    __syncthreads();
     {  // flush: 8 lanes per record
         const uint32_t w = tid & 7u;
         for (uint32_t sl = tid >> 3; sl < (uint32_t)kUpdSlots; sl += T / 8) {

@@ -242,7 +242,14 @@ int hfpf_node_process(hfpf_node* n, hfpf_trigger_response* res)
         }
     }
     if (rc != HFPF_OK) {
-        const std::string m = rc == HFPF_ERR_IO ? "cannot write " + cloud_location + " / " + meta_location : std::string(hfpf_last_error(n->grid));
+        std::string m = rc == HFPF_ERR_IO ? "cannot write " + cloud_location + " / " + meta_location : std::string(hfpf_last_error(n->grid));
+        // The reference ends getFusedCloud with grid_.clearVoxels() whatever happened before (node.cpp:438).  An engine failure
+        // (capacity overflow, poisoned handle) leaves nothing worth keeping and hfpf_clear is the only way out of that state, so
+        // the grid is cleared here too and the node can capture again without a restart; after an I/O error the fused data is
+        // intact and kept, so that ~process can be repeated once the directory is writable.
+        if (rc != HFPF_ERR_IO) {
+            if (hfpf_clear(n->grid) == HFPF_OK) m += " (grid cleared)";
+        }
         set_res(res, false, m);
         return nfail(n, rc, m);
     }

@@ -63,6 +63,12 @@ def all_agree(dist, ok):
     return bool(t.item())
 
 
+class DistError(RuntimeError):
+    """Raised on EVERY rank when any rank failed in front of a collective step: the step is abandoned everywhere, so no
+    rank is left waiting in an all-gather / all-reduce its peer never enters (the engine's RCCL path does the same with a
+    status word, csrc/hfpf.hip dist_status_gather_locked)."""
+
+
 def init_rccl(grid, dist, hfpf_mod):
     """Bootstrap the engine's RCCL communicator: rank 0 creates the id, the launcher's process group carries it.
     Returns (ok, error text).  Either every rank ends up with a communicator or none does."""
@@ -99,9 +105,23 @@ class HostStagedTransport:
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
 
+    def _consensus(self, err, what):
+        """Every rank calls this in front of a collective with its local outcome; either all proceed or all raise."""
+        if all_agree(self.dist, err is None):
+            return
+        if err is not None:
+            raise DistError("rank %d failed before the %s: %s" % (self.rank, what, err)) from err
+        raise DistError("another rank failed before the %s; the call is abandoned on every rank" % what)
+
     def exchange(self, grid):
-        ptr, n = grid.epoch_export()
-        mine = grid.device_download(ptr, n * EPOCH_REC_BYTES) if n else np.zeros(0, np.uint8)
+        err, mine = None, np.zeros(0, np.uint8)
+        try:
+            ptr, n = grid.epoch_export()
+            if n:
+                mine = grid.device_download(ptr, n * EPOCH_REC_BYTES)
+        except Exception as e:  # a poisoned / overflowed handle: tell the peers instead of leaving them in the all-gather
+            err = e
+        self._consensus(err, "epoch exchange")
         parts = allgather_bytes(self.dist, mine)
         foreign = [p for r, p in enumerate(parts) if r != self.rank and p.size]
         if foreign:
@@ -112,8 +132,19 @@ class HostStagedTransport:
             grid.device_free(dev)
 
     def merged_extract(self, grid):
-        p, n, pc, nc = grid.stats_export()
-        total = allreduce_words(self.dist, grid.device_download(p, n * 8, np.uint64))
+        err, mine, p, n, pc, nc = None, None, 0, 0, 0, 0
+        try:
+            p, n, pc, nc = grid.stats_export()
+            mine = grid.device_download(p, n * 8, np.uint64)
+        except Exception as e:
+            err = e
+        self._consensus(err, "statistics all-reduce of extract")
+        import torch
+        sizes = torch.tensor([n, -n], dtype=torch.int64)  # MAX of (n, -n) = (max n, -min n): equal record counts on every rank?
+        self.dist.all_reduce(sizes, op=self.dist.ReduceOp.MAX)
+        if int(sizes[0]) != -int(sizes[1]):
+            raise DistError("the ranks hold between %d and %d statistic words: they did not run the same clean schedule" % (-int(sizes[1]), int(sizes[0])))
+        total = allreduce_words(self.dist, mine)
         dev = grid.device_alloc(total.nbytes)
         grid.device_upload(dev, total)
         devc = 0
@@ -138,7 +169,15 @@ class LocalVirtualRanks:
         self.gathered = gathered
 
     def clean_all(self):
-        exports = [g.epoch_export() for g in self.grids]
+        exports, failed = [], []
+        for r, g in enumerate(self.grids):
+            try:
+                exports.append(g.epoch_export())
+            except Exception as e:  # same consensus as the real transports: one failed rank abandons the pass on all of them
+                exports.append((0, 0))
+                failed.append((r, e))
+        if failed:
+            raise DistError("rank %d failed before the epoch exchange: %s; the pass is abandoned on every rank" % failed[0]) from failed[0][1]
         if self.gathered:
             world = len(self.grids)
             counts = np.array([n for _, n in exports], dtype=np.uint64)
@@ -162,8 +201,11 @@ class LocalVirtualRanks:
     def extract(self, on=0):
         g0 = self.grids[on]
         tot = totc = None
-        for g in self.grids:
-            p, n, pc, nc = g.stats_export()
+        for r, g in enumerate(self.grids):
+            try:
+                p, n, pc, nc = g.stats_export()
+            except Exception as e:
+                raise DistError("rank %d failed before the statistics merge of extract: %s" % (r, e)) from e
             w = g.device_download(p, n * 8, np.uint64)
             tot = w if tot is None else (tot + w)  # uint64 wraparound add
             if nc:

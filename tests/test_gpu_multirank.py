@@ -199,3 +199,127 @@ def test_two_processes_one_stream_each_equal_single_process(hfpf_mod, synth_mod)
         single = one.extract()
         one.device_free(dev)
     assert single.tobytes() == res[0], "two processes differ from one process fusing both streams"
+
+
+def test_virtual_rank_failure_abandons_the_pass_on_every_rank(hfpf_mod, synth_mod):
+    """Failure consensus: rank 1 overflows its private point log; the epoch exchange of the next
+    clean must fail on EVERY rank (no rank cleans alone and then waits for the failed one at the following collective), and so
+    must the statistics merge of extract."""
+    import hfpf_dist
+    sc = scenes.Scene(2, 160, 120, 0.001, fx=615.0)
+    grids = [hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL),
+             hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **dict(SMALL, max_log_points=4096))]
+    vr = hfpf_dist.LocalVirtualRanks(grids)
+    try:
+        for r, g in enumerate(grids):
+            g.integrate(sc.frame(r), sc.poses[r])
+        with pytest.raises(hfpf_dist.DistError) as e:
+            vr.clean_all()
+        assert "rank 1 failed" in str(e.value) and "point log" in str(e.value)
+        assert [g.counters()["clean_passes"] for g in grids] == [0, 0]  # nobody went ahead
+        with pytest.raises(hfpf_dist.DistError) as e2:
+            vr.extract()
+        assert "rank 1 failed" in str(e2.value)
+        grids[1].clear()  # the way out, as for a single handle
+        for r, g in enumerate(grids):
+            g.clear()
+    finally:
+        for g in grids:
+            g.close()
+
+
+def test_rccl_world_size_one_poisoned_rank_returns_instead_of_blocking(hfpf_mod, synth_mod):
+    """The engine's own collectives with the failure-consensus status gather (dist_status_gather_locked) in front of them, at
+    the only world size this box can form: a rank whose clean pass failed (max_normals overflow) must come back from the next
+    hfpf_clean and from hfpf_extract with an error -- it enters the status all-gather with its fail bit set, which is what
+    keeps its peers from waiting in ncclAllGather / ncclAllReduce -- and hfpf_clear makes it usable again."""
+    sc = scenes.Scene(2, 160, 120, 0.001, fx=615.0)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **dict(SMALL, max_normals=256)) as g:
+        g.dist_init_rccl(0, 1, hfpf_mod.dist_unique_id())
+        g.integrate(sc.frame(0), sc.poses[0])
+        with pytest.raises(hfpf_mod.HfpfError) as e:
+            g.clean()
+        assert e.value.code == -3  # capacity, found in the middle of the pass (after the exchange)
+        for call in (g.clean, g.extract):
+            with pytest.raises(hfpf_mod.HfpfError) as e2:
+                call()
+            assert e2.value.code == -5 and "hfpf_clear" in str(e2.value)
+        g.clear()
+        assert len(g.extract()) == 0  # through the status gather + all-reduce again, healthy
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **dict(SMALL, max_log_points=4096)) as g:
+        g.dist_init_rccl(0, 1, hfpf_mod.dist_unique_id())
+        g.integrate(sc.frame(0), sc.poses[0])
+        with pytest.raises(hfpf_mod.HfpfError) as e:  # sticky overflow bit: found by the export in FRONT of the exchange
+            g.clean()
+        assert e.value.code == -3 and "point log" in str(e.value)
+        with pytest.raises(hfpf_mod.HfpfError):
+            g.extract()
+
+
+def _two_proc_failing_worker(rank, world, port, q, scene_kw):
+    """Like _two_proc_worker, but rank 1's point log is far too small: its export fails at the first collective clean."""
+    try:
+        import os
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        root = os.path.dirname(here)
+        for p in (os.path.join(root, "high-fidelity-pointcloud-fusion_amd", "python"), here):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        import hfpf
+        import hfpf_dist
+        import scenes
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sc = scenes.Scene(seed=0xF051 + 7919 * rank, pose_seed=0x5E3 + 104729 * rank, **scene_kw)
+        caps = dict(SMALL, max_log_points=4096) if rank == 1 else SMALL
+        g = hfpf.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **caps)
+        g.attach_transport(hfpf_dist.HostStagedTransport(dist))
+        g.integrate(sc.frame(0), sc.poses[0])
+        out = []
+        for call in (g.clean, g.extract):
+            try:
+                call()
+                out.append("no error")
+            except hfpf_dist.DistError as e:
+                out.append("mine" if "rank %d failed" % rank in str(e) else "peer")
+        q.put((rank, out))
+        g.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def test_two_processes_failure_on_one_rank_stops_both(hfpf_mod, synth_mod):
+    """Two OS processes on the GPU over the gloo host-staged transport, rank 1 overflowing its point log: both must return an
+    error from the collective clean and from the collective extract; a hang fails the test through its timeout."""
+    import multiprocessing as mp
+    import queue as queue_mod
+    import socket
+    kw = dict(n_frames=1, W=160, H=120, resolution=0.001, fx=615.0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_proc_failing_worker, args=(r, 2, port, q, kw)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in procs:
+            r, v = q.get(timeout=240)
+            res[r] = v
+    except queue_mod.Empty:
+        pass
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert res == {0: ["peer", "peer"], 1: ["mine", "mine"]}, res

@@ -191,3 +191,23 @@ def _with_rgb(rows, value):
     out = rows.copy()
     out["rgb"] = value
     return out
+
+
+def test_node_recovers_from_an_engine_failure_through_process(tmp_path, hfpf_mod, synth_mod):
+    """a capacity error poisons the engine handle; ~process must then report the failure AND clear the grid (the
+    reference always ends getFusedCloud with clearVoxels, node.cpp:438), so the node captures again without a restart."""
+    import hfpf_node
+    sc = scenes.Scene(2, 160, 120, 0.001, fx=615.0)
+    with hfpf_node.FusionNode(bounding_box=list(sc.bbox), directory_name=str(tmp_path), tf_lookup=lambda t, s: sc.poses[int(s)],
+                              resolution=sc.resolution, **dict(CAPS, max_normals=256)) as node:
+        node.start()
+        assert node.publish(sc.frame(0), 1, sc.W * sc.H, frame_id="0") == 1
+        with pytest.raises(hfpf_mod.HfpfError):  # more than 256 normals: the pass fails, the handle is poisoned
+            node.clean_now()
+        rc, ok, msg = node.process()
+        assert rc != 0 and not ok and "grid cleared" in msg
+        # usable again: an organised message is cut to its first row (160 points, too few cells for any normal)
+        assert node.publish(sc.frame(1), sc.H, sc.W, frame_id="1") == 1
+        assert node.clean_now() == 1
+        rc, ok, msg = node.process()
+        assert rc == 0 and ok and msg.startswith("saved 0 points")
