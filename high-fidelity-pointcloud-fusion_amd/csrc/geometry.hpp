@@ -148,6 +148,21 @@ HFPF_HD bool cylinder_member(const GridParams& g, F3 pt, F3 centre, F3 n, F3& pr
     return dist < g.cyl_r;
 }
 
+// dist = ||p - proj|| as the statistics see it (grid.hpp:261: Eigen's norm(), a correctly rounded f32 sqrt).
+// HFPF_EXACT_SQRT=1: the IEEE square root (hardware estimate + the compiler's fix-up, ~13 more instructions per pair);
+// 0: the 1-ulp hardware estimate -- membership never depends on it (decided on d2), only the mean_dist / sd_dist sums do.
+#ifndef HFPF_EXACT_SQRT
+#define HFPF_EXACT_SQRT 0
+#endif
+__device__ __forceinline__ float dist_sqrt(float d2)
+{
+#if HFPF_EXACT_SQRT
+    return sqrtf(d2);
+#else
+    return __builtin_amdgcn_sqrtf(d2);
+#endif
+}
+
 // The kernels' form.  Membership is decided on the squared distance: a correctly rounded sqrt is monotonic, so
 // (double)sqrtf(d2) < cyl_r  <=>  d2 <= d2_max with d2_max the largest f32 that passes (found by the host at create and
 // checked against the form above by the leaf tests) -- identical decisions without the IEEE sqrt refinement and the f64 compare.
@@ -157,7 +172,7 @@ __device__ __forceinline__ bool line_member(const GridParams& g, F3 pt, F3 a, F3
     F3 proj;
     float d2;
     line_project(pt, a, ab, dd, s, proj, d2);
-    distf = __builtin_amdgcn_sqrtf(d2);
+    distf = dist_sqrt(d2);
     return d2 <= g.d2_max;
 }
 
@@ -201,7 +216,7 @@ __device__ __forceinline__ bool line_member_hoisted(const GridParams& g, F3 pt, 
     const F3 proj = sub3(a, mul3(s, ab));
     const F3 df = sub3(pt, proj);
     const float d2 = dot3(df, df);
-    distf = __builtin_amdgcn_sqrtf(d2);
+    distf = dist_sqrt(d2);
     return d2 <= g.d2_max;
 }
 

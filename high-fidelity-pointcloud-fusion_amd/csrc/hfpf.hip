@@ -10,6 +10,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <dlfcn.h>
+#include <sched.h>
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <emmintrin.h>
@@ -54,13 +55,11 @@ struct StageSlot {  // pose / frame-id staging for one in-flight integrate call
     bool pending = false;
 };
 
-struct FrameSlot {  // host-frame staging (pinned + device)
+struct FrameSlot {  // host-frame staging: a pinned bounce buffer + one slot of the device ring (hfpf_handle::ring_d)
     void* h = nullptr;       // pinned bounce buffer (hfpf_integrate only; hfpf_integrate_pinned copies from the caller's memory)
     size_t cap_h = 0;
-    void* d = nullptr;
-    size_t cap = 0;
-    hipEvent_t done = nullptr;    // main stream: the kernels that read d have finished
-    hipEvent_t copied = nullptr;  // copy stream: the upload into d has finished
+    hipEvent_t done = nullptr;    // main stream: the kernels that read the slot have finished
+    hipEvent_t copied = nullptr;  // copy stream: the upload into the slot has finished
     bool pending = false;
 };
 
@@ -188,9 +187,14 @@ struct hfpf_handle {
     uint64_t n_linked[kLogRegions] = {0};  // per log region: entries already chained
     unsigned long long* h_log_ctr = nullptr;  // pinned mirror of the region counters
     int integrate_grid = 1536;
+    int upd_shape_forced = -1;  // HFPF_UPD_SHAPE
+    bool upd_wide = false;      // the 352-slot record table overflowed in this session: k_update_cells takes the 512-slot shape
+    unsigned long long upd_miss_seen = 0, upd_member_seen = 0;
     uint32_t launch_seq = 0;  // integrate launches so far (rotates the log append regions)
     uint64_t frames_integrated = 0;
-    uint64_t reg_done = 0;  // reg_occ entries already present in dep[]
+    bool normals_possible = false;   // a clean pass has run since the last clear (the host mirror of C_NORMALS may lag behind a no-wait pass)
+    bool small_sort = true;          // HFPF_SMALL_SORT=0: rocPRIM's default configuration for every size
+    bool clean_small_nowait = true;  // small clean passes run without a mid-pass read-back (HFPF_CLEAN_NOWAIT=0 restores it)
     uint64_t gate_done = 0; // occ_list entries already examined by a gate pass
     // A capacity / HIP / collective error in the middle of a clean pass leaves the tables half updated: the handle then refuses
     // further work (HFPF_ERR_STATE) until hfpf_clear, instead of silently losing candidates on a retry.
@@ -205,6 +209,20 @@ struct hfpf_handle {
     StageSlot stage[kStageSlots];
     int stage_next = 0;
     FrameSlot fslot[kFrameSlots];
+    // Device side of the host-frame path: ONE allocation of kFrameSlots slots, ring_cap bytes apart, so that consecutive slots
+    // form a batch k_integrate can take in one launch (frame_stride = ring_cap).  Frames that arrive while the engine's stream
+    // is still busy with earlier ones are uploaded at once but handed to the kernels together (up to host_batch of them): one
+    // bin plan, one k_integrate, one pass of the per-brick kernels for the lot instead of one each.  A frame that finds the
+    // stream idle is launched immediately, so a sensor slower than the engine sees no added latency.
+    void* ring_d = nullptr;
+    size_t ring_cap = 0;
+    uint32_t pend_n = 0, pend_first = 0;  // uploaded, not yet launched: slots [pend_first, pend_first + pend_n)
+    uint32_t pend_pts = 0;
+    uint32_t pend_lay[5] = {0, 0, 0, 0, 0};  // point_step, off_x, off_y, off_z, off_rgb of the pending frames
+    double pend_pose[kFrameSlots * 12];
+    int host_batch = 4;                   // HFPF_HOST_BATCH (1 = every frame launches on its own)
+    hipEvent_t busy_ev = nullptr;         // recorded behind the last launch of the host-frame path
+    bool busy_pending = false;
     bool update_cells = true;  // k_update_cells (cell-sorted form); HFPF_UPDATE_FORM=points: k_update (per-point form), A/B and tests
     StagePool* stage_pool = nullptr;  // created by the first large bounce copy (HFPF_STAGE_THREADS helpers, default 4; 0 = none)
     int stage_threads = -1;
@@ -215,6 +233,7 @@ struct hfpf_handle {
     unsigned long long* h_ctr = nullptr;  // pinned mirror of the counters
     unsigned long long* mbox = nullptr;   // coherent pinned mailbox k_publish_counters writes (HFPF_MAILBOX=0: blit copies + synchronize)
     unsigned long long mbox_seq = 0;
+    unsigned long long pub_seq = 0;  // sequence number of a publish enqueued behind the last integrate call and still current (0: none)
 
     // two-pass (binned) dependant update (default; HFPF_FLAG_DIRECT_UPDATE switches it off)
     bool binned = false;
@@ -222,6 +241,7 @@ struct hfpf_handle {
     double bin_prev_points = 0;   // points presented by that launch (to scale the plan)
     uint64_t bin_pool = 0;        // entries in bin_pt
     uint64_t n_bricks_known = 0;  // bricks allocated at the last counter read-back
+    float test_bin_scale = 1.f;   // tests only (HFPF_TEST_BIN_SCALE): shrinks the planned bin regions so that they overflow into the direct forms
     DevBuf bin_pt_buf, bin_rgb_buf;
 
     // multi-GPU: RCCL is resolved at run time so a single-GPU user needs no librccl
@@ -236,6 +256,10 @@ struct hfpf_handle {
 
     // kernel timing
     bool timing = false;
+    bool timing_detail = false;  // hfpf_kernel_timing(h, 2): also one event pair per kernel of an integrate call (ids 2..4)
+    std::vector<hipEvent_t> ev_detail;  // 4 events per call: before k_integrate, after it, after k_update*, after k_buffer
+    double t_detail_ms[3] = {0, 0, 0};
+    uint64_t n_detail[3] = {0, 0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending_clean;
     double t_clean_ms = 0;
@@ -341,9 +365,15 @@ __global__ __launch_bounds__(256) void k_publish_counters(const unsigned long lo
 int read_counters(hfpf_handle* h)
 {
     if (h->mbox) {
-        const unsigned long long seq = ++h->mbox_seq;
-        k_publish_counters<<<1, 256, 0, h->stream>>>(h->t.ctr, h->t.log_ctr, h->mbox, seq);
-        HIPCHK(h, hipGetLastError());
+        // An integrate call ends with a publish of its own (nothing has touched the counters since): the snapshot is already on
+        // its way, so the host only waits -- no launch of its own behind a stream that has just drained.
+        unsigned long long seq = h->pub_seq;
+        h->pub_seq = 0;
+        if (seq == 0) {
+            seq = ++h->mbox_seq;
+            k_publish_counters<<<1, 256, 0, h->stream>>>(h->t.ctr, h->t.log_ctr, h->mbox, seq);
+            HIPCHK(h, hipGetLastError());
+        }
         volatile unsigned long long* flag = h->mbox + kMboxWords + 7;
         for (uint64_t spins = 1;; spins++) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
@@ -441,8 +471,9 @@ int setup_params(hfpf_handle* h)
     // a cell on that voxel's line, so |t| <= K*res + sqrt(3)*res
     const double Bs = 0.5 + ((double)c.K + 2.0) * g.res / (2.0 * c.ball_radius);
     if (!(Bs < 1.0e6)) return fail(h, HFPF_ERR_BAD_CONFIG, "ball_radius too small for this resolution and K");
-    g.fs_scale = stat_scale_for(Bs);
-    g.fss_scale = stat_scale_for(Bs * Bs);
+    const double Bm = HFPF_CENTERED_MOMENTS ? Bs - 0.5 : Bs;  // bound of the accumulated variable (u = s - 0.5 or s, stats.hpp)
+    g.fs_scale = stat_scale_for(Bm);
+    g.fss_scale = stat_scale_for(Bm * Bm);
     g.fd_scale = stat_scale_for(g.cyl_r);
     g.fdd_scale = stat_scale_for(g.cyl_r * g.cyl_r);
     {   // largest f32 u with (double)sqrtf(u) < cyl_r (sqrtf is correctly rounded on the host: IEEE 754), by bisection on the bits
@@ -482,12 +513,16 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.bin_off, 0, 2 * (t.max_bricks + 2) * 4, s));
     HIPCHK(h, hipMemsetAsync(t.bin_capb, 0, 2 * (t.max_bricks + 2) * 4, s));
     h->bin_have_hist = false;
+    h->normals_possible = false;
+    h->pend_n = 0;
+    h->pub_seq = 0;
+    h->upd_wide = false;
+    h->upd_miss_seen = h->upd_member_seen = 0;
     h->direct_linked = 0;
     h->n_bricks_known = 0;
     if (h->h_ctr) memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));  // host mirror follows the device counters
     h->dirty = false;
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
-    h->reg_done = 0;
     h->gate_done = 0;
     h->pend_valid = false;
     h->poisoned = false;
@@ -553,6 +588,7 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(prereg_list, t.max_reg, 0, false);
     ALLOC(prechg_list, t.max_reg, 0, false);
     ALLOC(touched_list, h->max_touched, 0, false);
+    ALLOC(touched_old, h->max_touched, 0, false);
     ALLOC(cand_key, t.max_occ, 0, false);
     ALLOC(frame_vp, 3 * t.max_frames);
     ALLOC(ctr, C_COUNT);
@@ -568,10 +604,24 @@ int alloc_tables(hfpf_handle* h)
 
 // Cell keys: only the low GridParams::key_bits bits are significant (an all-ones sentinel still sorts behind every valid key:
 // a valid cell has x < dim <= 2^bits_x - 1, so its key is never all ones).
+// Small inputs (the candidate keys of a steady clean pass: a few 10^4): rocPRIM's default splits them into 1024-key blocks and
+// merges pairwise, nine launches of ~7 us for 40 k keys.  8192-key blocks (1024 threads x 8 keys) need one launch up to 8 k keys
+// and one block sort + three merges at 40 k.
+using SmallSortConfig = rocprim::radix_sort_config<rocprim::kernel_config<1024, 8>, rocprim::merge_sort_config<512, 1024, 8>, rocprim::default_config, 1024 * 1024>;
+constexpr uint64_t kSmallSortMax = 1ull << 17;  // (below rocPRIM's merge-path threshold: every merge pass is one launch)
+
 int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n)
 {
     const unsigned kb = h->g.key_bits;
     size_t bytes = 0;
+    if (n <= kSmallSortMax && h->small_sort) {
+        HIPCHK(h, rocprim::radix_sort_keys<SmallSortConfig>(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
+        int rc = scratch(h, h->sort_tmp, bytes);
+        if (rc) return rc;
+        bytes = h->sort_tmp.bytes;
+        HIPCHK(h, rocprim::radix_sort_keys<SmallSortConfig>(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, kb, h->stream));
+        return HFPF_OK;
+    }
     HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
@@ -580,14 +630,25 @@ int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n)
     return HFPF_OK;
 }
 
-int sort_keys_u32(hfpf_handle* h, uint32_t* in, uint32_t* out, uint64_t n)
+int sort_keys_u32(hfpf_handle* h, uint32_t* in, uint32_t* out, uint64_t n, unsigned bits = 32)
 {
     size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, 32, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, bits, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
     bytes = h->sort_tmp.bytes;
-    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, 32, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, bits, h->stream));
+    return HFPF_OK;
+}
+
+int sort_pairs_u32(hfpf_handle* h, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, uint64_t n, unsigned bits)
+{
+    size_t bytes = 0;
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, bits, h->stream));
+    int rc = scratch(h, h->sort_tmp, bytes);
+    if (rc) return rc;
+    bytes = h->sort_tmp.bytes;
+    HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0, bits, h->stream));
     return HFPF_OK;
 }
 
@@ -630,6 +691,21 @@ int acquire_stage(hfpf_handle* h, uint32_t n_frames, StageSlot** out)
     return HFPF_OK;
 }
 
+// Which instantiation of k_update_cells a launch takes (kernels.hpp, UpdShape): 0 dense, 1 wide table.  HFPF_UPD_SHAPE=0|1 forces
+// one.  Otherwise the dense shape, until the items that found no slot in its table exceed one in 500 member pairs (counted by the
+// kernel, seen by the host at its counter read-backs -- every clean pass); then the wide table for the rest of the session.
+int pick_update_shape(hfpf_handle* h, double points, uint32_t nb)
+{
+    (void)points;
+    (void)nb;
+    if (h->upd_shape_forced >= 0) return h->upd_shape_forced;
+    const unsigned long long miss = h->h_ctr[C_TABLE_MISS], member = h->h_ctr[C_DEP_MEMBER];
+    if (!h->upd_wide && miss > h->upd_miss_seen && (miss - h->upd_miss_seen) * 500ull > member - std::min(member, h->upd_member_seen)) h->upd_wide = true;
+    h->upd_miss_seen = miss;
+    h->upd_member_seen = member;
+    return h->upd_wide ? 1 : 0;
+}
+
 int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_frames, uint64_t frame_stride, uint32_t n_points,
                             uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double* poses,
                             const uint32_t* frame_ids)
@@ -641,6 +717,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     if (std::max(std::max(off_x, off_y), std::max(off_z, off_rgb)) + 4 > point_step)
         return fail(h, HFPF_ERR_BAD_ARG, "integrate: field offset beyond point_step");
     if (n_frames > 65535) return fail(h, HFPF_ERR_BAD_ARG, "integrate: at most 65535 frames per call");
+    h->pub_seq = 0;  // kernels are about to be enqueued: a counter snapshot already on its way is no longer the latest
     StageSlot* s = nullptr;
     int rc = acquire_stage(h, n_frames, &s);
     if (rc) return rc;
@@ -723,7 +800,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         h->t.bin_pt = (float4*)h->bin_pt_buf.p;
         h->t.bin_rgb = (uint32_t*)h->bin_rgb_buf.p;
         if (have_plan) {
-            const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points));
+            const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points)) * h->test_bin_scale;
             const uint32_t n_regions = 2u * (nb + 1u);  // two per brick: cells with / without a normal
             hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(n_regions, 256)), dim3(256), 0, h->stream, h->t, n_regions, scale);
             size_t bytes = 0;
@@ -732,13 +809,27 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
             if (rc2) return rc2;
             bytes = h->sort_tmp.bytes;
             HIPCHK(h, rocprim::exclusive_scan(h->sort_tmp.p, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_regions, rocprim::plus<uint32_t>(), h->stream));
-            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(n_regions, 256)), dim3(256), 0, h->stream, h->t, n_regions, h->bin_pool);
+            const uint32_t all_regions = 2u * (uint32_t)(h->t.max_bricks + 2);
+            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(all_regions, 256)), dim3(256), 0, h->stream, h->t, n_regions, all_regions, h->bin_pool);
         } else {  // no plan yet: no region exists, every lane takes the direct forms, the demand is recorded
             HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
             HIPCHK(h, hipMemsetAsync(h->t.bin_capb, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
         }
     }
     const uint32_t log_rot = (uint32_t)((h->launch_seq++ * 17u) & (kLogRegions - 1));
+    auto detail_mark = [&]() -> hipError_t {  // per-kernel boundaries of this call (detail timing only)
+        if (!h->timing_detail) return hipSuccess;
+        hipEvent_t e = nullptr;
+        if (!h->ev_free.empty()) {
+            e = h->ev_free.back();
+            h->ev_free.pop_back();
+        } else if (hipError_t r = hipEventCreate(&e)) {
+            return r;
+        }
+        h->ev_detail.push_back(e);
+        return hipEventRecord(e, h->stream);
+    };
+    HIPCHK(h, detail_mark());
 #define HFPF_LAUNCH_INTEGRATE(P, C, B)                                                                                                              \
     hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, lay, \
                        (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w, log_rot, probe)
@@ -747,23 +838,37 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, false);
         else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, false);
         else HFPF_LAUNCH_INTEGRATE(false, true, false);
+        for (int k = 0; k < 3; k++) HIPCHK(h, detail_mark());
     } else {
         if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, true);
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, true);
         else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, true);
         else HFPF_LAUNCH_INTEGRATE(false, true, true);
+        HIPCHK(h, detail_mark());
         if (have_plan) {
-            if (h->h_ctr[C_NORMALS] > 0) {  // as of the last clean: without a normal record no cell has dependants
+            if (h->h_ctr[C_NORMALS] > 0 || h->normals_possible) {  // without a normal record no cell has dependants
                 if (h->update_cells) {
-                    if (color) hipLaunchKernelGGL(k_update_cells<true>, dim3(nb), dim3(kUpd2Threads), 0, h->stream, h->g, h->t, nb);
-                    else hipLaunchKernelGGL(k_update_cells<false>, dim3(nb), dim3(kUpd2Threads), 0, h->stream, h->g, h->t, nb);
+                    const int shape = pick_update_shape(h, (double)n_points * n_frames, nb);
+#define HFPF_LAUNCH_UPDATE(S)                                                                                                             \
+    do {                                                                                                                                  \
+        if (color) hipLaunchKernelGGL((k_update_cells<true, S.threads, S.cap, S.slots, S.desc, S.waves>), dim3(nb), dim3(S.threads), 0, h->stream, h->g, h->t, nb); \
+        else hipLaunchKernelGGL((k_update_cells<false, S.threads, S.cap, S.slots, S.desc, S.waves>), dim3(nb), dim3(S.threads), 0, h->stream, h->g, h->t, nb);      \
+    } while (0)
+                    if (shape == 1) HFPF_LAUNCH_UPDATE(kUpdWide);
+                    else HFPF_LAUNCH_UPDATE(kUpdDense);
+#undef HFPF_LAUNCH_UPDATE
                 } else {
                     if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
                     else hipLaunchKernelGGL(k_update<false>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
                 }
             }
+            HIPCHK(h, detail_mark());
             if (color) hipLaunchKernelGGL(k_buffer<true>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
             else hipLaunchKernelGGL(k_buffer<false>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
+            HIPCHK(h, detail_mark());
+        } else {
+            HIPCHK(h, detail_mark());
+            HIPCHK(h, detail_mark());
         }
         h->bin_have_hist = true;
         h->bin_prev_points = (double)n_points * n_frames;
@@ -778,12 +883,19 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     s->pending = true;
     h->dirty = true;  // state_changed = true, grid.hpp:189
     h->frames_integrated += n_frames;
+    if (h->mbox && n_frames >= 4) {  // a batch: the next call is probably a clean pass, which starts by reading the counters
+        h->pub_seq = ++h->mbox_seq;
+        k_publish_counters<<<1, 256, 0, h->stream>>>(h->t.ctr, h->t.log_ctr, h->mbox, h->pub_seq);
+        HIPCHK(h, hipGetLastError());
+    } else {
+        h->pub_seq = 0;
+    }
     return HFPF_OK;
 }
 
 int resolve_timing(hfpf_handle* h)
 {
-    if (h->ev_pending.empty() && h->ev_pending_clean.empty()) return HFPF_OK;
+    if (h->ev_pending.empty() && h->ev_pending_clean.empty() && h->ev_detail.empty()) return HFPF_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& pr : h->ev_pending_clean) {
         float ms = 0.f;
@@ -803,6 +915,16 @@ int resolve_timing(hfpf_handle* h)
         h->ev_free.push_back(pr.second);
     }
     h->ev_pending.clear();
+    for (size_t i = 0; i + 3 < h->ev_detail.size(); i += 4) {
+        for (int k = 0; k < 3; k++) {
+            float ms = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&ms, h->ev_detail[i + k], h->ev_detail[i + k + 1]));
+            h->t_detail_ms[k] += (double)ms;
+            h->n_detail[k]++;
+        }
+    }
+    for (hipEvent_t e : h->ev_detail) h->ev_free.push_back(e);
+    h->ev_detail.clear();
     return HFPF_OK;
 }
 
@@ -885,6 +1007,7 @@ int epoch_export_locked(hfpf_handle* h, uint64_t* n_out, uint64_t min_capacity_r
 int epoch_import_locked(hfpf_handle* h, const void* dev_records, uint64_t n)
 {
     if (n == 0) return HFPF_OK;
+    h->pub_seq = 0;  // the import changes counters behind any snapshot already on its way
     hipLaunchKernelGGL(k_epoch_import, dim3(blocks_for(n, 256 * kRegTiles)), dim3(256), 0, h->stream, h->g, h->t, (const EpochRec*)dev_records, n);
     HIPCHK(h, hipGetLastError());
     return HFPF_OK;
@@ -1045,11 +1168,11 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     if (n_in == 0) return HFPF_OK;
     if ((rc = scratch(h, h->pend_b, n_in * 4))) return rc;
     if ((rc = scratch(h, h->keys_a, n_in * 8))) return rc;
-    hipLaunchKernelGGL(k_set_ctr3, dim3(1), dim3(1), 0, s, t.ctr, (int)C_CAND, 0ull, (int)C_PEND, 0ull, (int)C_PRECHG, 0ull);
-    HIPCHK(h, hipMemsetAsync(t.cand_key, 0xFF, n_in * 8, s));  // all-ones sentinels behind the real candidates: they sort to the end
+    hipLaunchKernelGGL(k_clean_begin, dim3(blocks_for(n_in, 256)), dim3(256), 0, s, t, n_in);  // sentinels + the pass's list counters
     launch_gate(h, (const uint32_t*)h->pend_a.p, n_pend, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, (uint32_t*)h->pend_b.p);
     HIPCHK(h, hipGetLastError());
     h->gate_done = n_occ;
+    h->normals_possible = true;
     std::swap(h->pend_a, h->pend_b);  // cells that got a normal in this pass are dropped by the next gate's kNormal test
     h->pend_valid = true;             // C_PEND now counts pend_a; the host reads it at the start of the next pass
 
@@ -1059,28 +1182,47 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     const uint64_t reg_tile = 256ull * kRegTiles;  // step-major, whole workgroups (kRegTiles tiles each) per step
     const uint64_t reg_blocks = ((n_in + reg_tile - 1) / reg_tile) * (2ull * (uint64_t)h->g.K + 1ull);
     hipLaunchKernelGGL(k_register, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals);
-    hipLaunchKernelGGL(k_commit_normals, dim3(1), dim3(1), 0, s, t, n_normals);
     HIPCHK(h, hipGetLastError());
     // The registration counts of this pass are bounded by (2K+1) * n_in; the kernels below read the exact counts from the
     // device counters (kCountOnDevice), and the host picks the values up at the read-back after them.
     const uint64_t reg_ub = (2ull * (uint64_t)h->g.K + 1ull) * n_in;
     uint64_t n_reg = 0, n_pre = 0, inc_touched = 0;
+    // registrations already present in dep[]: every pass files all of its own, so that is the counter as this pass found it
+    const uint64_t reg_first = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
     // incremental update; a conservative space estimate decides whether to compact instead (C_DEP as of the last readback:
     // nothing has changed it since)
-    bool full = h->h_ctr[C_DEP] + 8 * reg_ub + reg_ub > t.max_dep;
+    // What one incremental update can take from dep[]: every relocated list (at most all live entries: registrations + single
+    // entries so far) plus two entries per registration bound of this pass.
+    const uint64_t live_ub = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg) + std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
+    bool full = h->h_ctr[C_DEP] + live_ub + 3 * reg_ub > t.max_dep;
+    // A pass is SMALL when its upper bounds are: then the replay is launched over the bound and reads the touched-cell count on
+    // the device, and the host does not wait for the pass at all (no mid-pass read-back: the GPU is not left idle for a host
+    // round trip, and the next integrate call is enqueued behind the replay at once).  The bound above makes sure the pass
+    // cannot run out of dep[] half-way (the one overflow the host would have to repair by compacting).
+    const bool no_wait = !full && reg_ub < (1ull << 21) && h->clean_small_nowait;
     if (!full) {
-        hipLaunchKernelGGL(k_depinc_count, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, h->reg_done, kCountOnDevice);
+        const unsigned count_blocks = blocks_for(reg_ub, 256 * kListTiles);
+        hipLaunchKernelGGL(k_depinc_count_pre, dim3(2 * count_blocks), dim3(256), 0, s, t, reg_first, kCountOnDevice, kCountOnDevice, count_blocks);
         hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, kCountOnDevice);
-        hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(reg_ub, 256)), dim3(256), 0, s, t, h->reg_done, kCountOnDevice);
-        hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(reg_ub, 256)), dim3(256), 0, s, t, kCountOnDevice);
-        hipLaunchKernelGGL(k_depinc_pre, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, kCountOnDevice);
+        hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(reg_ub, 256)), dim3(256), 0, s, t, reg_first, kCountOnDevice);
         HIPCHK(h, hipGetLastError());
+        if (no_wait) {  // errors of this pass (capacity) surface at the next read-back and poison the handle there
+            if (t.color)
+                hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(reg_ub * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)t.touched_list,
+                                   (const uint32_t*)t.touched_old, kCountOnDevice, n_normals);
+            else
+                hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(reg_ub * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)t.touched_list,
+                                   (const uint32_t*)t.touched_old, kCountOnDevice, n_normals);
+            HIPCHK(h, hipGetLastError());
+            return HFPF_OK;
+        }
         if ((rc = read_counters(h))) return rc;
         n_reg = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
         n_pre = std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
         inc_touched = h->h_ctr[C_TOUCHED];
         if (h->h_ctr[C_ERR] == (unsigned long long)E_DEP) {  // dep[] ran out mid-way: compact
             hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(1), 0, s, t.ctr, (int)C_ERR, 0ull);
+            if (inc_touched) hipLaunchKernelGGL(k_dep_reset, dim3(blocks_for(inc_touched, 256)), dim3(256), 0, s, t, inc_touched);  // poisoned cursors
             full = true;
         } else if ((rc = check_device_errors(h))) {
             return rc;
@@ -1117,18 +1259,26 @@ int clean_locked(hfpf_handle* h, int pre_rc)
         // a 256-point tile appends consecutive log entries for neighbouring cells, so walking the cells in slot (brick-major)
         // order lets adjacent lanes share cache lines of the log; a short list is not worth the sort's nine launches
         const uint32_t* cells = t.touched_list;
+        const uint32_t* olds = full ? nullptr : t.touched_old;  // (a compacting rebuild leaves the lists in no particular order)
         if (inc_touched >= (1ull << 18)) {
             if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
-            if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched))) return rc;
+            unsigned slot_bits = 9;  // slot = brick * 512 + cell; the brick count is as of the read-back just above
+            while ((1ull << slot_bits) < (h->n_bricks_known + 2) * (uint64_t)kBrickCells && slot_bits < 32) slot_bits++;
+            if (olds) {
+                if ((rc = scratch(h, h->vals_b, inc_touched * 4))) return rc;
+                if ((rc = sort_pairs_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, t.touched_old, (uint32_t*)h->vals_b.p, inc_touched, slot_bits))) return rc;
+                olds = (const uint32_t*)h->vals_b.p;
+            } else if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched, slot_bits))) {
+                return rc;
+            }
             cells = (const uint32_t*)h->vals_a.p;
         }
         if (t.color)
-            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, olds, inc_touched, n_normals);
         else
-            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, inc_touched, n_normals);
+            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, olds, inc_touched, n_normals);
         HIPCHK(h, hipGetLastError());
     }
-    h->reg_done = n_reg;
     return HFPF_OK;
 }
 
@@ -1195,6 +1345,11 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
     {
         const char* uf = getenv("HFPF_UPDATE_FORM");
         h->update_cells = !(uf && uf[0] == 'p');
+        if (const char* hb = getenv("HFPF_HOST_BATCH")) h->host_batch = std::max(1, std::min(atoi(hb), kFrameSlots));
+        if (const char* us = getenv("HFPF_UPD_SHAPE")) h->upd_shape_forced = std::max(0, std::min(atoi(us), 1));
+        if (const char* ss = getenv("HFPF_SMALL_SORT")) h->small_sort = ss[0] != '0';
+        if (const char* nw = getenv("HFPF_CLEAN_NOWAIT")) h->clean_small_nowait = nw[0] != '0';
+        if (const char* bs = getenv("HFPF_TEST_BIN_SCALE")) h->test_bin_scale = std::max(0.f, std::min(1.f, (float)atof(bs)));
         const char* mb = getenv("HFPF_MAILBOX");
         if (!mb || mb[0] != '0') {
             if ((e = hipHostMalloc((void**)&h->mbox, (kMboxWords + 8) * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess)
@@ -1254,10 +1409,11 @@ int hfpf_destroy(hfpf_handle* h)
     h->stage_pool = nullptr;
     for (auto& f : h->fslot) {
         if (f.h) (void)hipHostFree(f.h);
-        if (f.d) (void)hipFree(f.d);
         if (f.done) (void)hipEventDestroy(f.done);
         if (f.copied) (void)hipEventDestroy(f.copied);
     }
+    if (h->ring_d) (void)hipFree(h->ring_d);
+    if (h->busy_ev) (void)hipEventDestroy(h->busy_ev);
     if (h->copy_stream) {
         (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamDestroy(h->copy_stream);
@@ -1270,6 +1426,7 @@ int hfpf_destroy(hfpf_handle* h)
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (auto e : h->ev_detail) (void)hipEventDestroy(e);
     for (auto e : h->ev_free) (void)hipEventDestroy(e);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_log_ctr) (void)hipHostFree(h->h_log_ctr);
@@ -1287,59 +1444,110 @@ int hfpf_get_dims(const hfpf_handle* h, int32_t dims[3], double* resolution)
     return HFPF_OK;
 }
 
+static int flush_pending_locked(hfpf_handle* h);
+
 int hfpf_integrate_device(hfpf_handle* h, const void* dev_base, uint32_t n_frames, uint64_t frame_stride, uint32_t n_points, uint32_t point_step,
                           uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double* poses, const uint32_t* frame_ids)
 {
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     if (int rc = check_usable(h)) return rc;
     return integrate_device_locked(h, dev_base, n_frames, frame_stride, n_points, point_step, off_x, off_y, off_z, off_rgb, poses, frame_ids);
 }
 
-// One host frame: upload on the copy stream into the next slot of the device staging ring, integrate on the main stream
-// behind it.  The upload of frame k+1 overlaps the kernels of frame k; `bounce` = copy the caller's (pageable) buffer into the
-// slot's pinned buffer first, so that the caller's memory is free again when the call returns.
+// Hand the uploaded-but-not-launched host frames to the kernels: one integrate launch for the batch.
+static int flush_pending_locked(hfpf_handle* h)
+{
+    if (h->pend_n == 0) return HFPF_OK;
+    const uint32_t first = h->pend_first, n = h->pend_n;
+    h->pend_n = 0;
+    if (h->poisoned) return HFPF_OK;  // the handle refuses work until hfpf_clear: the frames are dropped like any later one
+    FrameSlot& last = h->fslot[first + n - 1];
+    HIPCHK(h, hipStreamWaitEvent(h->stream, last.copied, 0));  // the copy stream is in order: the earlier uploads are done too
+    int rc = integrate_device_locked(h, (const char*)h->ring_d + (size_t)first * h->ring_cap, n, h->ring_cap, h->pend_pts, h->pend_lay[0], h->pend_lay[1],
+                                     h->pend_lay[2], h->pend_lay[3], h->pend_lay[4], h->pend_pose, nullptr);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < n; k++) {
+        FrameSlot& f = h->fslot[first + k];
+        HIPCHK(h, hipEventRecord(f.done, h->stream));
+        f.pending = true;
+    }
+    if (!h->busy_ev) HIPCHK(h, hipEventCreateWithFlags(&h->busy_ev, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->busy_ev, h->stream));
+    h->busy_pending = true;
+    return HFPF_OK;
+}
+
+// One host frame: upload on the copy stream into the next slot of the device ring; launch it -- together with the frames still
+// waiting in front of it -- when the engine's stream is idle or the batch is full, otherwise leave it pending (the next frame,
+// or any other call on the handle, launches it).  The upload of frame k+1 overlaps the kernels of frame k; `bounce` = copy the
+// caller's (pageable) buffer into the slot's pinned buffer first, so that the caller's memory is free again when the call returns.
 static int integrate_host_locked(hfpf_handle* h, const void* base, bool bounce, uint32_t n_points, uint32_t point_step, uint32_t off_x,
                                  uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double pose[12])
 {
     if (!base || !pose) return fail(h, HFPF_ERR_BAD_ARG, "integrate: null buffer or pose");
     if (int rc0 = check_usable(h)) return rc0;
+    int rc;
     if (n_points == 0) {
+        if ((rc = flush_pending_locked(h))) return rc;  // frame ids stay in arrival order
         h->next_frame_id++;
         h->frames_integrated++;
         h->dirty = true;
         return HFPF_OK;
     }
+    if ((point_step & 3) || (off_x & 3) || (off_y & 3) || (off_z & 3) || (off_rgb & 3))
+        return fail(h, HFPF_ERR_BAD_ARG, "integrate: fields must be 4-byte aligned");
+    if (std::max(std::max(off_x, off_y), std::max(off_z, off_rgb)) + 4 > point_step)
+        return fail(h, HFPF_ERR_BAD_ARG, "integrate: field offset beyond point_step");
+    const uint32_t lay[5] = {point_step, off_x, off_y, off_z, off_rgb};
     const size_t bytes = (size_t)n_points * point_step;
-    FrameSlot& f = h->fslot[h->fslot_next];
+    // a frame of another shape, or a slot that is not the batch's neighbour (ring wrap), closes the pending batch
+    if (h->pend_n && (h->pend_pts != n_points || memcmp(h->pend_lay, lay, sizeof lay) != 0 || (uint32_t)h->fslot_next != h->pend_first + h->pend_n)) {
+        if ((rc = flush_pending_locked(h))) return rc;
+    }
+    if (h->ring_cap < bytes) {  // (re)size the ring: nothing may be in flight in it
+        if ((rc = flush_pending_locked(h))) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (auto& f : h->fslot) f.pending = false;
+        if (h->ring_d) {
+            HIPCHK(h, hipFree(h->ring_d));
+            h->device_bytes -= h->ring_cap * kFrameSlots;
+        }
+        h->ring_d = nullptr;
+        h->ring_cap = 0;
+        const size_t cap = (bytes + 4095) & ~(size_t)4095;
+        HIPCHK(h, hipMalloc(&h->ring_d, cap * kFrameSlots));
+        h->ring_cap = cap;
+        h->device_bytes += cap * kFrameSlots;
+        h->fslot_next = 0;
+    }
+    const uint32_t slot = (uint32_t)h->fslot_next;
+    FrameSlot& f = h->fslot[slot];
     h->fslot_next = (h->fslot_next + 1) % kFrameSlots;
-    if (f.pending) {  // the kernels that read this slot's device buffer (kFrameSlots frames ago)
+    if (f.pending) {  // the kernels that read this slot (kFrameSlots frames ago)
         HIPCHK(h, hipEventSynchronize(f.done));
         f.pending = false;
     }
     if (!f.done) HIPCHK(h, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
     if (!f.copied) HIPCHK(h, hipEventCreateWithFlags(&f.copied, hipEventDisableTiming));
-    const size_t cap = (bytes + 4095) & ~(size_t)4095;
-    if (f.cap < bytes) {
-        if (f.d) HIPCHK(h, hipFree(f.d));
-        f.d = nullptr;
-        HIPCHK(h, hipMalloc(&f.d, cap));
-        f.cap = cap;
-    }
     const void* src = base;
     if (bounce) {
         if (f.cap_h < bytes) {
             if (f.h) HIPCHK(h, hipHostFree(f.h));
             f.h = nullptr;
-            HIPCHK(h, hipHostMalloc(&f.h, cap, hipHostMallocDefault));
-            f.cap_h = cap;
+            HIPCHK(h, hipHostMalloc(&f.h, h->ring_cap, hipHostMallocDefault));
+            f.cap_h = h->ring_cap;
         }
         // the caller's buffer is free again when this call returns
         if (h->stage_threads < 0) {
             const char* e = getenv("HFPF_STAGE_THREADS");
-            const int hw = (int)std::thread::hardware_concurrency();
-            h->stage_threads = e ? std::max(0, std::min(atoi(e), 15)) : std::max(0, std::min(4, hw / 2 - 1));
+            int cores = (int)std::thread::hardware_concurrency();
+            cpu_set_t set;
+            if (sched_getaffinity(0, sizeof set, &set) == 0) cores = std::min(cores > 0 ? cores : 1 << 20, CPU_COUNT(&set));  // the process's share
+            h->stage_threads = e ? std::max(0, std::min(atoi(e), 15)) : std::max(0, std::min(7, cores / 2 - 1));
         }
         if (h->stage_threads > 0 && bytes >= (1u << 20)) {
             if (!h->stage_pool) h->stage_pool = new StagePool(h->stage_threads);
@@ -1349,14 +1557,27 @@ static int integrate_host_locked(hfpf_handle* h, const void* base, bool bounce, 
         }
         src = f.h;
     }
-    HIPCHK(h, hipMemcpyAsync(f.d, src, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipMemcpyAsync((char*)h->ring_d + (size_t)slot * h->ring_cap, src, bytes, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(f.copied, h->copy_stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, f.copied, 0));
-    int rc = integrate_device_locked(h, f.d, 1, 0, n_points, point_step, off_x, off_y, off_z, off_rgb, pose, nullptr);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(f.done, h->stream));
-    f.pending = true;
-    return HFPF_OK;
+    if (h->pend_n == 0) {
+        h->pend_first = slot;
+        h->pend_pts = n_points;
+        memcpy(h->pend_lay, lay, sizeof lay);
+    }
+    memcpy(h->pend_pose + 12 * h->pend_n, pose, 12 * sizeof(double));
+    h->pend_n++;
+    h->dirty = true;  // state_changed = true, grid.hpp:189 (the frame is accepted; its kernels follow)
+    bool launch = h->pend_n >= (uint32_t)std::max(1, h->host_batch) || h->fslot_next == 0;  // batch full, or the ring wraps next
+    if (!launch) {
+        if (!h->busy_pending) {
+            launch = true;
+        } else {
+            const hipError_t q = hipEventQuery(h->busy_ev);
+            if (q == hipSuccess) h->busy_pending = false, launch = true;
+            else if (q != hipErrorNotReady) HIPCHK(h, q);
+        }
+    }
+    return launch ? flush_pending_locked(h) : HFPF_OK;
 }
 
 int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
@@ -1399,6 +1620,7 @@ int hfpf_host_free(hfpf_handle* h, void* host_ptr)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipHostFree(host_ptr));
@@ -1417,6 +1639,7 @@ int hfpf_clean(hfpf_handle* h)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     const int pre = check_usable(h);
     if (pre && !h->dist_on) return pre;
     if (!h->timing || pre) return poison_on_error(h, clean_locked(h, pre));
@@ -1487,6 +1710,7 @@ int hfpf_extract_filtered(hfpf_handle* h, const hfpf_extract_opts* opts, hfpf_ro
     if (opts && opts->struct_size != sizeof(hfpf_extract_opts)) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     *rows = nullptr;
     *n_rows = 0;
     Tables& t = h->t;
@@ -1521,6 +1745,7 @@ int hfpf_extract_with_stats(hfpf_handle* h, const void* dev_words, const void* d
     if (!h || !rows || !n_rows || !dev_words) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     *rows = nullptr;
     *n_rows = 0;
     int rc = read_counters(h);
@@ -1535,6 +1760,7 @@ int hfpf_stats_export(hfpf_handle* h, const void** dev_words, uint64_t* n_words,
     if (!h || !dev_words || !n_words) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     int rc = check_usable(h);
     if (!rc) rc = read_counters(h);
     if (!rc) rc = poison_on_error(h, check_device_errors(h));
@@ -1551,6 +1777,7 @@ int hfpf_epoch_export(hfpf_handle* h, const void** dev_records, uint64_t* n_reco
     if (!h || !dev_records || !n_records) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     uint64_t n = 0;
     int rc = check_usable(h);
     if (!rc) rc = epoch_export_locked(h, &n, 0);
@@ -1566,6 +1793,7 @@ int hfpf_epoch_import(hfpf_handle* h, const void* dev_records, uint64_t n_record
     if (!h || (!dev_records && n_records)) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     int rc = epoch_import_locked(h, dev_records, n_records);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));  // the caller may reuse / free the record buffer
@@ -1578,6 +1806,7 @@ int hfpf_epoch_import_gathered(hfpf_handle* h, const void* dev_buffer, uint64_t 
     if (!h || !dev_buffer || !counts || world < 1 || my_rank < 0 || my_rank >= world) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     if (int rc0 = check_usable(h)) return rc0;
     std::vector<unsigned long long> c(counts, counts + world);
     int rc = import_gathered_locked(h, dev_buffer, slice_stride_bytes, world, my_rank, c.data());
@@ -1671,6 +1900,7 @@ int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, ui
     if (!h || !host_dst || !dev_src) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return HFPF_OK;
@@ -1800,6 +2030,7 @@ int hfpf_clear(hfpf_handle* h)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->pend_n = 0;  // host frames still waiting for their launch would be wiped with the rest
     int rc = reset_state(h);
     h->dirty = true;  // clearVoxels sets state_changed, grid.hpp:169
     return rc;
@@ -1810,6 +2041,7 @@ int hfpf_sync(hfpf_handle* h)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     int rc = read_counters(h);
     if (rc) return rc;
     return poison_on_error(h, check_device_errors(h));
@@ -1820,6 +2052,7 @@ int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)
     if (!h || !out) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     int rc = read_counters(h);
     if (rc) return rc;
     const unsigned long long* c = h->h_ctr;
@@ -1846,6 +2079,7 @@ int hfpf_get_occupied(hfpf_handle* h, int32_t* xyz, uint64_t cap, uint64_t* n_ou
     if (!h || !n_out) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     int rc = read_counters(h);
     if (rc) return rc;
     const uint64_t n = std::min<uint64_t>(h->h_ctr[C_OCC], h->t.max_occ);
@@ -1896,10 +2130,13 @@ int hfpf_kernel_timing(hfpf_handle* h, int enable)
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     int rc = resolve_timing(h);
     if (rc) return rc;
     h->timing = enable != 0;
+    h->timing_detail = enable == 2;
     if (enable) {
+        for (int k = 0; k < 3; k++) h->t_detail_ms[k] = 0, h->n_detail[k] = 0;
         h->t_integrate_ms = 0;
         h->n_integrate_launches = 0;
         h->t_clean_ms = 0;
@@ -1910,11 +2147,17 @@ int hfpf_kernel_timing(hfpf_handle* h, int enable)
 
 int hfpf_get_kernel_time(hfpf_handle* h, int kernel_id, double* total_ms, uint64_t* launches)
 {
-    if (!h || kernel_id < 0 || kernel_id > 1) return HFPF_ERR_BAD_ARG;
+    if (!h || kernel_id < 0 || kernel_id > 4) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     int rc = resolve_timing(h);
     if (rc) return rc;
+    if (kernel_id >= 2) {
+        if (total_ms) *total_ms = h->t_detail_ms[kernel_id - 2];
+        if (launches) *launches = h->n_detail[kernel_id - 2];
+        return HFPF_OK;
+    }
     if (total_ms) *total_ms = kernel_id == 0 ? h->t_integrate_ms : h->t_clean_ms;
     if (launches) *launches = kernel_id == 0 ? h->n_integrate_launches : h->n_clean_timed;
     return HFPF_OK;

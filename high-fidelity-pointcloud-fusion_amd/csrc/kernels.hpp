@@ -551,45 +551,77 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
 // An item finds its work with two dependent LDS reads (round 2: a 9-step binary search over the item prefix sums, i.e. nine
 // dependent LDS reads per item, ~1000 cycles of latency in front of every entry read).  Items beyond the descriptor array
 // (kUpd2Desc per round) and entries past 32766 keep the search.
-#ifndef HFPF_UPD2_THREADS
-#define HFPF_UPD2_THREADS 512
-#endif
-#ifndef HFPF_UPD2_CAP
-#define HFPF_UPD2_CAP 1024  // points sorted per round (LDS: 16 bytes each)
-#endif
 #ifndef HFPF_UPD2_CHUNK
 #define HFPF_UPD2_CHUNK 8  // points of a cell one work item takes
-#endif
-#ifndef HFPF_UPD2_WAVES
-#define HFPF_UPD2_WAVES 1
-#endif
-#ifndef HFPF_UPD2_DESC
-#define HFPF_UPD2_DESC 1024  // work items of a round that get a descriptor (4 bytes each)
 #endif
 #ifndef HFPF_UPD2_ABL
 #define HFPF_UPD2_ABL 0  // TIMING-ONLY ablations (the results are wrong): 1 no table insert, 2 no pair loop, 3 no items, 4 loads only
 #endif
-constexpr int kUpd2Threads = HFPF_UPD2_THREADS, kUpd2Cap = HFPF_UPD2_CAP, kUpd2Chunk = HFPF_UPD2_CHUNK, kUpd2Desc = HFPF_UPD2_DESC;
-static_assert(kUpd2Threads == 256 || kUpd2Threads == 512 || kUpd2Threads == 1024, "k_update_cells: one or two cells per scanning thread");
-static_assert(kUpd2Cap % kUpd2Threads == 0 && kUpd2Chunk >= 1 && kUpd2Chunk <= 15, "k_update_cells: int32 item sums hold 15 contributions");
-static_assert(kUpd2Cap <= 4095 && (kUpd2Cap + kUpd2Chunk - 1) / kUpd2Chunk <= 256, "k_update_cells: cell record holds 12-bit positions, descriptor 8-bit chunks");
+constexpr int kUpd2Chunk = HFPF_UPD2_CHUNK;
+static_assert(kUpd2Chunk >= 1 && kUpd2Chunk <= 15, "k_update_cells: int32 item sums hold 15 contributions");
 constexpr uint32_t kUpd2NoDesc = ~0u;
+// The kernel is a chain of latencies per brick (dependent loads, four barriers a round), so what decides its speed is how many
+// bricks a CU works on at once, i.e. its LDS footprint -- and that is dominated by the record table (44 bytes a slot) and the
+// sorted points (12 bytes each).  Two shapes are instantiated and the host picks per launch (hfpf.hip pick_update_shape):
+//   kUpdDense  512 threads, 1024 points a round, 352-slot table: 40 KB, FOUR workgroups (32 waves, 64 VGPRs) per CU.  Bricks that
+//              update ~100 records each: the 640x480 @ 1 mm bench (591 us per 150-frame launch against 624 with the wide table).
+//   kUpdWide   512 threads, 1024 points, 512 slots: 47 KB, three workgroups.  Taken for the rest of the session once the small
+//              table has overflowed more than rarely (the kernel counts the items that found no slot, the host sees the count at
+//              its counter read-backs): 0.5 mm voxels put 200-300 records on a brick, and an item without a slot costs five
+//              scattered memory-side atomics (2048 x 1536 @ 0.5 mm: 1.47 ms per launch wide, 2.35 ms dense).
+// Measured and dropped: 256 threads with 512-point rounds for bricks with few points (1.9 ms on that workload: the barriers cost
+// less, the lanes per brick are missed more).  The table takes any size (the hash is range-reduced with a multiply, not masked).
+struct UpdShape {
+    int threads, cap, slots, desc, waves;
+};
+constexpr UpdShape kUpdDense{512, 1024, 352, 1024, 8}, kUpdWide{512, 1024, 512, 1024, 6};
 
-template <bool COLOR>
-__global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(const GridParams g, const Tables t, const uint32_t n_bricks)
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP data path: four row shifts and two row broadcasts, six VALU
+// instructions and no LDS traffic (__shfl_up is a ds_bpermute per step: ~60 cycles of LDS-crossbar latency each, in a chain).
+#ifndef HFPF_DPP_SCAN
+#define HFPF_DPP_SCAN 1
+#endif
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 {
+#if HFPF_DPP_SCAN
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1, zero shifted in
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+#else
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(v, o);
+        if (lane >= (uint32_t)o) v += a;
+    }
+    return v;
+#endif
+}
+
+template <bool COLOR, int THREADS, int CAP, int SLOTS, int DESC, int WAVES>
+__global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParams g, const Tables t, const uint32_t n_bricks)
+{
+    static_assert(THREADS == 256 || THREADS == 512 || THREADS == 1024, "k_update_cells: one or two cells per scanning thread");
+    static_assert(CAP % THREADS == 0 && CAP <= 4095 && (CAP + kUpd2Chunk - 1) / kUpd2Chunk <= 256, "k_update_cells: cell record holds 12-bit positions, descriptor 8-bit chunks");
+    constexpr int kUpd2Threads = THREADS, kUpd2Cap = CAP, kUpd2Slots = SLOTS, kUpd2Desc = DESC;
+    auto upd2_hash = [](uint32_t sid) -> uint32_t { return __umulhi(sid * 2654435761u, (uint32_t)SLOTS); };
     constexpr int W = COLOR ? 8 : kStatUsed;
     constexpr uint32_t T = kUpd2Threads, NW = T / 64, CPT = T >= kBrickCells ? 1 : kBrickCells / T, PER = kUpd2Cap / T, CH = kUpd2Chunk;
-    __shared__ float4 s_pts[kUpd2Cap];
+    __shared__ float s_px[kUpd2Cap], s_py[kUpd2Cap], s_pz[kUpd2Cap];  // sorted points, one array per coordinate (12 bytes a point)
     __shared__ uint32_t s_rgb[COLOR ? kUpd2Cap : 1];
     __shared__ uint32_t s_cnt[kBrickCells];
     __shared__ uint64_t s_pack[kBrickCells];       // per cell and round: dependant-list offset (32) | first sorted position (12) | points (12)
     __shared__ uint32_t s_items[kBrickCells + 1];  // first work item of each cell (only the search path and the total read it)
     __shared__ uint32_t s_desc[kUpd2Desc];         // per work item: cell (9) | chunk (8) | entry (15)
     __shared__ uint32_t s_wsum[2][NW];
-    __shared__ uint32_t keys[kUpdSlots];
-    __shared__ unsigned long long vals[kUpdSlots * W];
-    __shared__ unsigned int blk_ctr[2];
+    __shared__ uint32_t keys[kUpd2Slots];
+    __shared__ unsigned long long vals[kUpd2Slots * W];
+    __shared__ unsigned int blk_ctr[3];
     const uint32_t b = blockIdx.x + 1;
     if (b > n_bricks) return;
     const uint32_t fill_a = min(t.bin_fill[2 * b], t.bin_capb[2 * b]), fill_b = min(t.bin_fill[2 * b + 1], t.bin_capb[2 * b + 1]);
@@ -607,11 +639,11 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
         own_off[k] = (uint32_t)(info >> kDepOffShift);  // dep[] stays below 2^32 entries (host-checked)
     }
     for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += T) s_cnt[i] = 0;
-    for (uint32_t i = tid; i < (uint32_t)kUpdSlots; i += T) keys[i] = 0;
-    for (uint32_t i = tid; i < (uint32_t)(kUpdSlots * W); i += T) vals[i] = 0;
-    if (tid < 2) blk_ctr[tid] = 0;
+    for (uint32_t i = tid; i < (uint32_t)kUpd2Slots; i += T) keys[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t)(kUpd2Slots * W); i += T) vals[i] = 0;
+    if (tid < 3) blk_ctr[tid] = 0;
     const float4* __restrict__ dep4 = reinterpret_cast<const float4*>(t.dep);
-    uint32_t c_tested = 0, c_member = 0;
+    uint32_t c_tested = 0, c_member = 0, c_miss = 0;
     // Software pipeline: the points of round r+1 are read from the bin while round r's items are worked, and an item's dependant
     // entry is read one item ahead (the first one of a round ahead of the scatter).
     float4 pt[PER];
@@ -696,12 +728,8 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
                 sum_n += n[k];
                 sum_it += it[k];
             }
-            inc_n = sum_n, inc_it = sum_it;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t a = __shfl_up(inc_n, o), c2 = __shfl_up(inc_it, o);
-                if (lane >= (uint32_t)o) inc_n += a, inc_it += c2;
-            }
+            inc_n = wave_inclusive_scan(sum_n);
+            inc_it = wave_inclusive_scan(sum_it);
             if (lane == 63) s_wsum[0][wave] = inc_n, s_wsum[1][wave] = inc_it;
         }
         __syncthreads();
@@ -737,13 +765,15 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
         for (uint32_t k = 0; k < PER; k++)
             if (tid + k * T < n_round) {
                 const uint32_t pos = (uint32_t)((s_pack[__float_as_uint(pt[k].w) & (kBrickCells - 1)] >> 32) & 0xFFFu) + rk[k];
-                s_pts[pos] = pt[k];
+                s_px[pos] = pt[k].x;
+                s_py[pos] = pt[k].y;
+                s_pz[pos] = pt[k].z;
                 if (COLOR) s_rgb[pos] = col[k];
             }
         __syncthreads();
         if (r0 + (uint32_t)kUpd2Cap < fill) load_round(r0 + (uint32_t)kUpd2Cap);  // in flight during the items
         // 5. items.  No barrier behind them: the next round's histogram only touches s_cnt, and its first barrier keeps every
-        // writer of s_pack / s_desc / s_pts behind the last reader of this round.
+        // writer of s_pack / s_desc / the sorted points behind the last reader of this round.
         for (uint32_t item = tid; item < total; item += T) {
             const Item cur = nxt;
             if (item + T < total) locate(item + T, nxt);
@@ -754,10 +784,10 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
             c_member += (__float_as_uint(cur.e0.x) ^ __float_as_uint(cur.e1.w) ^ __float_as_uint(la.x) ^ __float_as_uint(lab.x) ^ __float_as_uint(dv.r)) & 1u;
 #else
             F3 qn = F3{0.f, 0.f, 0.f};  // the next point of the run is read while this one is tested
-            if (cur.p_lo < cur.p_hi) qn = *reinterpret_cast<const F3*>(&s_pts[cur.first + cur.p_lo]);
+            if (cur.p_lo < cur.p_hi) qn = F3{s_px[cur.first + cur.p_lo], s_py[cur.first + cur.p_lo], s_pz[cur.first + cur.p_lo]};
             for (uint32_t pi = cur.p_lo; pi < cur.p_hi; pi++) {
                 const F3 q3 = qn;
-                if (pi + 1 < cur.p_hi) qn = *reinterpret_cast<const F3*>(&s_pts[cur.first + pi + 1]);
+                if (pi + 1 < cur.p_hi) qn = F3{s_px[cur.first + pi + 1], s_py[cur.first + pi + 1], s_pz[cur.first + pi + 1]};
                 float sp, distf;
                 if (!line_member_hoisted(g, q3, la, lab, dv, sp, distf)) continue;
                 const PairDelta q = pair_delta(g, sp, distf);
@@ -782,7 +812,7 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
 #endif
             if (a_n == 0) continue;
             const uint32_t sid = __float_as_uint(cur.e0.x);
-            uint32_t h = upd_hash(sid);
+            uint32_t h = upd2_hash(sid);
             bool placed = false;
             for (int probe = 0; probe < ((t.test_table_skip & sid) ? 0 : 16); probe++) {
                 const uint32_t old = atomicCAS(&keys[h], 0u, sid);
@@ -790,8 +820,9 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
                     placed = true;
                     break;
                 }
-                h = (h + 1) & (kUpdSlots - 1);
+                h = h + 1 == (uint32_t)kUpd2Slots ? 0u : h + 1;
             }
+            c_miss += placed ? 0u : 1u;  // the host widens the table when this stops being rare
             unsigned long long* sv = placed ? &vals[h * W] : nullptr;
             unsigned long long* gv = &t.stats[(uint64_t)sid * kStatWords];  // table full: straight to HBM
 #define HFPF_UPD2_ADD(word, val)                                                \
@@ -813,7 +844,7 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
     __syncthreads();
     {  // flush: 8 lanes per record
         const uint32_t w = tid & 7u;
-        for (uint32_t sl = tid >> 3; sl < (uint32_t)kUpdSlots; sl += T / 8) {
+        for (uint32_t sl = tid >> 3; sl < (uint32_t)kUpd2Slots; sl += T / 8) {
             const uint32_t key = keys[sl];
             if (key != 0u && w < (uint32_t)W) atomicAdd(&t.stats[(uint64_t)key * kStatWords + w], vals[sl * W + w]);
         }
@@ -822,14 +853,17 @@ __global__ __launch_bounds__(kUpd2Threads, HFPF_UPD2_WAVES) void k_update_cells(
     for (int o = 32; o > 0; o >>= 1) {
         c_tested += __shfl_down(c_tested, o);
         c_member += __shfl_down(c_member, o);
+        c_miss += __shfl_down(c_miss, o);
     }
     if (lane == 0) {
         if (c_tested) atomicAdd(&blk_ctr[0], c_tested);
         if (c_member) atomicAdd(&blk_ctr[1], c_member);
+        if (c_miss) atomicAdd(&blk_ctr[2], c_miss);
     }
     __syncthreads();
     if (tid < 2 && blk_ctr[tid])
         atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
+    if (tid == 2 && blk_ctr[2]) atomicAdd(&t.ctr[C_TABLE_MISS], (unsigned long long)blk_ctr[2]);  // rare by construction
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -910,17 +944,21 @@ __global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t
     uint32_t cap = 0;
     if (r >= 2) {
         const uint32_t demand = t.bin_fill[r & ~1u] + t.bin_fill[r | 1u];
-        if (demand) cap = (uint32_t)((float)demand * scale * 1.25f) + 64u;
+        if (demand) cap = (uint32_t)fminf((float)demand * scale * 1.25f, 2.0e9f) + 64u;  // (saturated: a float above 2^32 does not convert)
     }
     t.bin_capb[r] = cap;
 }
 
-// After the exclusive scan of the capacities: regions that do not fit the pool are switched off.
-__global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_t n_regions, const uint64_t pool)
+// After the exclusive scan of the capacities: regions that do not fit the pool are switched off, and the demand counters of ALL
+// regions restart -- also those of bricks the host has not heard of yet (claimed since its last counter read-back: they have no
+// region until then and keep recording their demand): left alone, their counters would add up over every launch until the next
+// clean pass and the plan made from them would be inflated by that factor.  With every counter holding ONE launch's demand the
+// planned capacities add up to at most 2.5 x points + 128 x bricks < the pool size, so the 32-bit scan cannot wrap.
+__global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_t n_regions, const uint32_t all_regions, const uint64_t pool)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_regions) return;
-    if ((uint64_t)t.bin_off[r] + t.bin_capb[r] > pool) t.bin_capb[r] = 0;
+    if (r >= all_regions) return;
+    if (r < n_regions && (uint64_t)t.bin_off[r] + t.bin_capb[r] > pool) t.bin_capb[r] = 0;
     t.bin_fill[r] = 0;
 }
 
@@ -1061,12 +1099,18 @@ __device__ __forceinline__ uint64_t cand_count(const Tables& t, uint64_t base)
     const uint64_t room = t.max_normals > base ? t.max_normals - base : 0;
     return n < room ? n : room;
 }
-// After k_normal / k_register: publish the new record count, reset the touched-cell counter of the dependant-table update.
-__global__ void k_commit_normals(const Tables t, const uint64_t base)
+// Head of a clean pass, one launch: all-ones sentinels behind the candidate keys the gate is about to write (they sort to the
+// end) and the pass's list counters back to zero.
+__global__ __launch_bounds__(256) void k_clean_begin(const Tables t, const uint64_t n_in)
 {
-    if (t.ctr[C_CAND] > cand_count(t, base)) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_NORMALS);
-    t.ctr[C_NORMALS] = base + cand_count(t, base);
-    t.ctr[C_TOUCHED] = 0;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_in) t.cand_key[i] = ~0ull;
+    if (i == 0) {
+        t.ctr[C_CAND] = 0;
+        t.ctr[C_PEND] = 0;
+        t.ctr[C_PRECHG] = 0;
+        t.ctr[C_TOUCHED] = 0;
+    }
 }
 
 // K4: one thread per candidate, in ascending key order; record id = base + rank + 1.
@@ -1077,6 +1121,10 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
     // candidates are all-ones sentinels
     const uint64_t n_cand = n_cand_arg == kCountOnDevice ? cand_count(t, base) : n_cand_arg;
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0 && n_cand_arg == kCountOnDevice) {  // publish the new record count (nothing in this pass reads it on the device)
+        if (t.ctr[C_CAND] > n_cand) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_NORMALS);
+        t.ctr[C_NORMALS] = base + n_cand;
+    }
     if (r >= n_cand) return;
     const uint64_t key = sorted_keys[r];
     int32_t x, y, z;
@@ -1223,10 +1271,15 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
 // Random 16-byte chain reads are the cost (sector amplification makes them HBM-bound), so reading each entry once
 // instead of once per registrant is the lever.  Runs after the dependant table has been updated.
 template <bool COLOR>
-__global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint64_t n_touched, const uint64_t base)
+__global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint32_t* __restrict__ olds,
+                                                const uint64_t n_touched_arg, const uint64_t base)
 {
+    // olds (may be null): per touched cell, the length its dependant list had before this pass.  The incremental update appends, so
+    // the registrants of this pass are the entries behind that position and the walk over the older ones -- one dependent 32-byte
+    // read each -- is skipped.  Without it (compacting rebuild: any order) every entry is looked at and filtered by record id.
     __shared__ unsigned long long queue[4][kQueueRows * kQueueStride];
     unsigned long long* q = queue[threadIdx.x >> 6];
+    const uint64_t n_touched = n_touched_arg == kCountOnDevice ? (uint64_t)t.ctr[C_TOUCHED] : n_touched_arg;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t j = gid / kChains;           // cell
     const uint32_t sub = (uint32_t)(gid % kChains);  // which of the cell's interleaved chains this lane walks
@@ -1247,6 +1300,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     }
     uint32_t replayed = 0;
     uint32_t next = 0;  // next dependant entry to look at
+    if (olds && j < n_touched) next = min(olds[j], cnt);
     // wave-uniform outer loop: every lane keeps calling the flush helper until all lanes are done
     while (__ballot(next < cnt) != 0) {
         constexpr int B = HFPF_REPLAY_B;
@@ -1254,36 +1308,36 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         F3 la[B], lab[B];
         float ldd[B];
         LineDiv ldv[B];
-        int m = 0;
+        bool use[B];
+        const float4* __restrict__ dep4 = reinterpret_cast<const float4*>(t.dep);
+        float4 e0[B], e1[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) {
-            sid[k] = 0;
-            la[k] = F3{0.f, 0.f, 0.f};
-            lab[k] = F3{0.f, 0.f, 1.f};
-            ldd[k] = 1.f;
-        }
-        while (next < cnt && m < B) {  // gather up to B registrants of this pass
-            const DepEntry e = t.dep[off + next];
-            next++;
-            if (e.sid > base) {
-#pragma unroll
-                for (int k = 0; k < B; k++)
-                    if (k == m) {
-                        sid[k] = e.sid;
-                        la[k] = F3{e.ax, e.ay, e.az};
-                        lab[k] = F3{e.abx, e.aby, e.abz};
-                        ldd[k] = e.dd;
-                    }
-                m++;
+        for (int k = 0; k < B; k++) {  // the next B entries, B independent reads in flight together
+            e0[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            e1[k] = make_float4(0.f, 0.f, 1.f, 1.f);
+            if (next + (uint32_t)k < cnt) {
+                e0[k] = dep4[2 * (off + next + k)];
+                e1[k] = dep4[2 * (off + next + k) + 1];
             }
         }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            sid[k] = __float_as_uint(e0[k].x);
+            use[k] = next + (uint32_t)k < cnt && sid[k] > base;  // a registrant of this pass
+            any = any || use[k];
+            la[k] = F3{e0[k].y, e0[k].z, e0[k].w};
+            lab[k] = F3{e1[k].x, e1[k].y, e1[k].z};
+            ldd[k] = e1[k].w;
+        }
+        next = min(cnt, next + (uint32_t)B);
         StatDeltaT<COLOR> d[B];
 #pragma unroll
         for (int k = 0; k < B; k++) {
             stat_delta_zero(d[k]);
             ldv[k] = line_div_of(ldd[k]);  // the divisor's share of the division, once per registrant (geometry.hpp)
         }
-        if (m > 0) {
+        if (any) {
             uint32_t e = head;
             while (e) {
                 const float4 p = t.log_pt[e];
@@ -1291,7 +1345,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
                 const F3 pt = F3{p.x, p.y, p.z};
 #pragma unroll
                 for (int k = 0; k < B; k++) {
-                    if (k < m) {
+                    if (use[k]) {
                         float sp, distf;
                         if (line_member_hoisted(g, pt, la[k], lab[k], ldv[k], sp, distf)) stat_delta_add(d[k], pair_delta(g, sp, distf), rgb);
                     }
@@ -1418,14 +1472,14 @@ __global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_
 // until the next full rebuild (k_dep_count / k_dep_offsets / k_dep_fill), which the host runs when dep[]
 // fills up.
 
-__global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg)
+__device__ __forceinline__ void depinc_count_body(const Tables& t, const uint64_t reg_first, const uint64_t n_reg_arg, const uint32_t block)
 {
     const uint64_t n_reg = n_reg_arg == kCountOnDevice ? min((uint64_t)t.ctr[C_REG], t.max_reg) : n_reg_arg;
     uint32_t slot_[kListTiles];
     uint32_t f_fresh = 0;
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
-        const uint64_t j = reg_first + ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        const uint64_t j = reg_first + ((uint64_t)block * kListTiles + tt) * 256u + threadIdx.x;
         slot_[tt] = 0;
         if (j < n_reg) {
             slot_[tt] = t.reg_occ[j].x;
@@ -1472,12 +1526,14 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
         if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask) {  // host falls back to a full (compacting) rebuild
             atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
             t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
+            t.touched_old[j] = 0;
             continue;
         }
         for (uint32_t k = 0; k < old_cnt; k++) t.dep[off + k] = t.dep[old_off + k];
         t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
         if (old_cnt == 0 && new_cnt) set_dep_flag(t, slot);
-        t.dep_tmp[slot] = old_cnt;  // append cursor
+        t.dep_tmp[slot] = old_cnt;     // append cursor
+        t.touched_old[j] = old_cnt;    // the entries behind it are this pass's registrants: where k_replay starts reading
     }
 }
 
@@ -1491,10 +1547,13 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
     if (k & 0x80000000u) return;
     const uint64_t info = t.info[r.x];
     t.dep[(info >> kDepOffShift) + k] = make_dep_entry(t, r.y);
+    // exactly (new length - old length) tickets are drawn per cell: whoever draws the last one leaves the scratch word at zero
+    // for the next pass (k_dep_reset only runs in front of a compacting rebuild now)
+    if (k + 1 == (uint32_t)((info >> kDepCntShift) & kDepCntMask)) t.dep_tmp[r.x] = 0;
 }
 
 // Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).
-__global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64_t n_chg_arg)
+__device__ __forceinline__ void depinc_pre_body(const Tables& t, const uint64_t n_chg_arg, const uint32_t block)
 {
     const uint64_t n_chg = n_chg_arg == kCountOnDevice ? min((uint64_t)t.ctr[C_PRECHG], t.max_reg) : n_chg_arg;
     uint32_t slot_[kListTiles];
@@ -1502,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
     uint32_t f_fresh = 0;
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
-        const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        const uint64_t j = ((uint64_t)block * kListTiles + tt) * 256u + threadIdx.x;
         slot_[tt] = 0, info_[tt] = 0;
         if (j < n_chg) {
             slot_[tt] = t.prechg_list[j];
@@ -1518,7 +1577,7 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
     block_reserve_tiles<kListTiles>(&t.ctr[C_DEP], n_f, noff, trs);
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
-        const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
+        const uint64_t j = ((uint64_t)block * kListTiles + tt) * 256u + threadIdx.x;
         if (j >= n_chg) continue;
         const uint32_t slot = slot_[tt];
         const uint64_t info = info_[tt];
@@ -1534,6 +1593,16 @@ __global__ __launch_bounds__(256) void k_depinc_pre(const Tables t, const uint64
         }
         t.dep[off] = make_dep_entry(t, t.pre_dep[slot]);
     }
+}
+
+// The two list builders that open the incremental update are independent of each other (occupied targets: count the new
+// entries per cell; unoccupied targets: set / replace their single entry) and share one launch: blocks [0, count_blocks) count,
+// the rest handle the unoccupied targets.  Both only reserve space in dep[] with atomics, in any order.
+__global__ __launch_bounds__(256) void k_depinc_count_pre(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg, const uint64_t n_chg_arg,
+                                                          const uint32_t count_blocks)
+{
+    if (blockIdx.x < count_blocks) depinc_count_body(t, reg_first, n_reg_arg, blockIdx.x);
+    else depinc_pre_body(t, n_chg_arg, blockIdx.x - count_blocks);
 }
 
 // ---- K6 extract -----------------------------------------------------------------------------------
@@ -1617,11 +1686,12 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
         const double ax = l0.x, ay = l0.y, az = l0.z, abx = l0.w, aby = l1.x, abz = l1.y;
         const double inv = 1.0 / (double)cnt;
         // every projection is a - s*ab (stats.hpp): centroid = a - E[s]*ab, per-axis variance = ab_i^2 * var(s)
-        const double es = ((double)s[SW_S] / (double)g.fs_scale) * inv;
+        const double em = ((double)s[SW_S] / (double)g.fs_scale) * inv;  // mean of s, or of u = s - 0.5 (stats.hpp)
+        const double es = HFPF_CENTERED_MOMENTS ? 0.5 + em : em;
         r.x = (float)(ax - es * abx);
         r.y = (float)(ay - es * aby);
         r.z = (float)(az - es * abz);
-        double vs = ((double)s[SW_SS] / (double)g.fss_scale) * inv - es * es;
+        double vs = ((double)s[SW_SS] / (double)g.fss_scale) * inv - em * em;
         const double md = ((double)s[SW_D] / (double)g.fd_scale) * inv;
         double vd = ((double)s[SW_DD] / (double)g.fdd_scale) * inv - md * md;
         if (cnt == 1) vs = vd = 0.0;  // the recurrence gives exactly 0 for a single sample

@@ -67,6 +67,7 @@ enum Ctr : int {
     C_REPLAY_MEMBER, // buffered points that fell inside a cylinder during clean-time replay
     C_PEND,         // occupied cells still without a normal after the running gate pass
     C_PRECHG,       // unoccupied cells whose single dependant changed in the running clean pass
+    C_TABLE_MISS,   // work items of k_update_cells that found no slot in the LDS record table (they update HBM directly)
     C_COUNT = 32
 };
 
@@ -119,6 +120,7 @@ struct Tables {
     uint32_t* prereg_list;
     uint32_t* prechg_list;
     uint32_t* touched_list;
+    uint32_t* touched_old;   // per touched_list entry: the cell's dependant-list length before the running pass
     uint64_t* cand_key;    // clean scratch (unsorted / sorted ping-pong handled by the host)
     float* frame_vp;       // 3 per frame id
     unsigned long long* ctr;

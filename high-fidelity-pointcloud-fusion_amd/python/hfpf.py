@@ -419,7 +419,8 @@ class OccupancyGrid:
         self._chk(lib().hfpf_device_upload(self._h, C.c_void_p(dev_ptr), _p(arr), arr.nbytes))
 
     def kernel_timing(self, enable=True):
-        self._chk(lib().hfpf_kernel_timing(self._h, 1 if enable else 0))
+        """True / 1: integrate calls and clean passes; 2: also each kernel of an integrate call (kernel_time ids 2..4)."""
+        self._chk(lib().hfpf_kernel_timing(self._h, int(enable)))
 
     def kernel_time(self, kernel_id=0):
         ms = C.c_double()

@@ -243,8 +243,10 @@ int hfpf_device_download(hfpf_handle* h, void* host_dst, const void* dev_src, ui
 int hfpf_device_copy(hfpf_handle* h, void* dev_dst, const void* dev_src, uint64_t bytes); /* device to device, synchronous */
 
 /* ---- measurement: HIP-event timing of the engine's own kernels on the engine's stream ----
- * kernel ids: 0 = k_integrate launches, 1 = whole clean passes (first to last kernel of hfpf_clean, host read-backs
- * included).  total_ms / launches accumulate since enable. */
+ * kernel ids: 0 = integrate calls (bin plan + k_integrate + k_update_cells + k_buffer), 1 = whole clean passes (first to last
+ * kernel of hfpf_clean, host read-backs included).  enable = 2 additionally brackets the kernels of every integrate call:
+ * 2 = k_integrate, 3 = k_update_cells / k_update, 4 = k_buffer (three more event records per call: use it for a breakdown
+ * pass, not for the headline timing).  total_ms / launches accumulate since enable. */
 int hfpf_kernel_timing(hfpf_handle* h, int enable);
 int hfpf_get_kernel_time(hfpf_handle* h, int kernel_id, double* total_ms, uint64_t* launches);
 

@@ -130,6 +130,33 @@ def test_config1_full_1000_frames(hfpf_mod, synth_mod):
         assert ctr[k] == ctr2[k], k
 
 
+@pytest.mark.slow
+def test_bench_cadence_stream_vs_oracle_and_overflowing_bins(oracle_mod, hfpf_mod, synth_mod, monkeypatch):
+    """The bench's cadence against the ORACLE: 120 frames of 640x480 (36.9 M points), 60 frames per integrate
+    call, clean every 60 frames, 16x16-pixel tiles -- 10^3..10^4 parked points per brick, several sort rounds per brick in
+    k_update_cells, the dry run of the first call, dependant-table relocation in the second and third clean pass.  The oracle
+    runs the same stream serially on the host (~30 s).  Second engine run: bin regions planned at a third of their demand
+    (HFPF_TEST_BIN_SCALE), so that most points of every brick overflow into the direct forms of k_integrate (direct log append +
+    chained entry, wave-cooperative atomic flush per member pair) beside the binned ones -- same rows, byte for byte."""
+    sc = scenes.Scene(120, 640, 480, 0.001, clean_every=60)
+    caps = dict(max_bricks=100000, max_log_points=48 << 20, max_normals=6 << 20, max_frames=256, frame_width=640)
+    rows, ctr, dims = _stream(hfpf_mod, sc, 60, caps)
+    assert ctr["clean_passes"] == 2 and ctr["dep_pairs_tested"] > 2e7 and len(rows) > 500000
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ref = scenes.run(og, sc, "capture")
+    oc = og.counters()
+    og.close()
+    assert (oc["presented"], oc["zclip_pass"], oc["inserted"], oc["buffered"]) == (
+        ctr["points_presented"], ctr["points_zclip_pass"], ctr["points_in_bbox"], ctr["points_buffered"])
+    scenes.compare_rows(ref, rows)
+    monkeypatch.setenv("HFPF_TEST_BIN_SCALE", "0.33")
+    rows2, ctr2, _ = _stream(hfpf_mod, sc, 60, caps)
+    scenes.compare_rows(ref, rows2)
+    assert rows.tobytes() == rows2.tobytes(), "overflowing bin regions (direct forms) changed the result"
+    for k in ("points_buffered", "dep_pairs_tested", "dep_pairs_member", "replay_members", "voxels_with_normal"):
+        assert ctr[k] == ctr2[k], k
+
+
 @pytest.mark.parametrize("color", [False, True])
 def test_update_forms_cell_sorted_and_per_point_give_the_same_bits(hfpf_mod, synth_mod, monkeypatch, color):
     """k_update_cells (points counting-sorted by cell in LDS, several rounds of 1024 points per brick at this size; default) against

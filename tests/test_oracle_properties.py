@@ -73,3 +73,23 @@ def test_membership_is_rotation_consistent(seed, n):
     clear = np.abs(rad - 0.001) > 5e-6
     assert np.array_equal((dist < 0.001)[clear], (rad < 0.001)[clear])
     assert np.allclose(dist, rad, atol=2e-6)
+
+
+def test_mean_dist_recurrence_carries_its_own_rounding_noise():
+    """Why `mean_dist` is compared at rtol 2e-5 and not tighter.  The reference keeps mean_dist as an f32 and
+    updates it once per cylinder member: mean_dist = (float)(mean_dist + (dist - mean_dist) / count) (grid.hpp:272), so every
+    sample adds one f32 rounding of the running value.  Over a few thousand samples those roundings random-walk to a few 1e-6
+    relative -- the deviation the GPU suite measures between the oracle and the engine's exact integer mean (4.6e-6, unchanged
+    when the engine takes the IEEE square root instead of the 1-ulp hardware one: profiles/r03_exactness.md).  An order-free
+    sum cannot reproduce a sequential rounding history; this test pins the size of that history with nothing but numpy."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for n in (500, 2000, 8000):
+        for _ in range(40):
+            dist = np.sqrt(rng.uniform(0.0, 1.0e-6, n).astype(np.float32))  # f32 distances below the 1 mm radius
+            m = np.float32(0.0)
+            for k, d in enumerate(dist.astype(np.float64), 1):
+                m = np.float32(np.float64(m) + (d - np.float64(m)) / k)  # double intermediates, one narrowing per update
+            exact = float(dist.astype(np.float64).mean())
+            worst = max(worst, abs(float(m) - exact) / exact)
+    assert 2e-7 < worst < 2e-5, worst  # well above one f32 ulp (6e-8), inside the asserted tolerance

@@ -2,7 +2,9 @@
 """Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh (one counter set per pass, as MI355X_MICROARCH.md prescribes) for
 the integrate hot path: k_integrate (decode / clip / transform / insert / park) + k_update (per-brick LDS accumulation).
 
-usage: python tools/pmc_summary.py gpurun_out/<prefix> profiles/r02_pmc_hot_path
+usage: python tools/pmc_summary.py gpurun_out/<mem prefix> profiles/r03_pmc_hot_path [gpurun_out/<sq prefix>]
+(the optional third argument adds the SQ counters of k_update_cells -- instruction counts, active lanes, LDS bank conflicts --
+as section "sq", which bench.py turns into roofline.compute)
 
 Each pass ran `bench.py --repeats 1 --warmup 0 --cpu-sample 0 --host-path-frames 0`: the 1000-frame configs[1] stream, one
 hfpf_integrate_device call per clean epoch.  k_integrate dispatches: #0 = the dry run of the session's first 8 frames (bin
@@ -52,6 +54,27 @@ def series(per, kernel, counter):
     return [d[i] for i in sorted(d)]
 
 
+def sq_section(sq_prefix):
+    """Means over the steady launches of k_update_cells (all but the last, 100-frame one) + the pairs one such launch tests."""
+    per = load(sq_prefix)
+    out = {}
+    for c, d in per["k_update"].items():
+        v = [d[i] for i in sorted(d)]
+        v = v[:-1] if len(v) > 1 else v
+        out[c] = sum(v) / len(v)
+    pairs = None
+    for f in sorted(glob.glob(sq_prefix + "_*.json")):
+        try:
+            line = json.loads(open(f).read().strip().splitlines()[-1])
+            pairs = line["counters"]["dep_pairs_tested"] * FRAMES_PER_LAUNCH / float(line["config"]["frames"] - FRAMES_PER_LAUNCH)
+            break
+        except Exception:
+            continue
+    if out.get("SQ_THREAD_CYCLES_VALU") and out.get("SQ_ACTIVE_INST_VALU"):
+        out["active_lane_fraction"] = out["SQ_THREAD_CYCLES_VALU"] / (out["SQ_ACTIVE_INST_VALU"] * 64.0)
+    return {"k_update": out, "pairs_per_launch": pairs}
+
+
 def main():
     prefix, out = sys.argv[1], sys.argv[2]
     per = load(prefix)
@@ -73,16 +96,21 @@ def main():
         corr = 0.5 * 16 * pts + 0.5 * 16 * in_bbox_frac * pts
         traffic = fa + fb + fc + corr + wa + wb + wc
         hit = lambda g: g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1.0)
+        steady = sel_b is not None
         res[phase] = {
-            "k_integrate": {"fetch_bytes_raw": fa, "write_bytes": wa, "atomic_requests": aa, "l2_hit_rate": hit(ga)},
-            "k_update": {"fetch_bytes_raw": fb, "write_bytes": wb, "atomic_requests": ab, "l2_hit_rate": hit(gb) if sel_b else None},
-            "k_buffer": {"fetch_bytes_raw": fc, "write_bytes": wc, "atomic_requests": ac, "l2_hit_rate": hit(gc)},
+            "k_integrate": {"fetch_bytes_raw": fa, "write_bytes": wa, "atomic_requests": aa, "l2_hit_rate": hit(ga), "fetch_correction_bytes": 0.5 * 16 * pts},
+            "k_update": {"fetch_bytes_raw": fb, "write_bytes": wb, "atomic_requests": ab, "l2_hit_rate": hit(gb) if sel_b else None,
+                         "fetch_correction_bytes": 0.5 * 16 * in_bbox_frac * pts if steady else 0.0},
+            "k_buffer": {"fetch_bytes_raw": fc, "write_bytes": wc, "atomic_requests": ac, "l2_hit_rate": hit(gc),
+                         "fetch_correction_bytes": 0.0 if steady else 0.5 * 16 * in_bbox_frac * pts},
             "fetch_correction_bytes": corr,
             "atomic_requests": aa + ab + ac,
             "traffic_bytes_per_launch": traffic,
             "traffic_bytes_per_point": traffic / pts,
             "algorithmic_bytes_per_launch": 32 * pts,
         }
+    if len(sys.argv) > 3:
+        res["sq"] = sq_section(sys.argv[3])
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
         f.write("# Integrate hot path: memory-side counters (rocprofv3 --pmc, one counter set per pass)\n\n")
