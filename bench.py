@@ -350,9 +350,13 @@ def main():
             calls = max(per_kernel["k_integrate"][1], 1)
             pairs_per_call = ctr["dep_pairs_tested"] / calls
             d_bar = ctr["dep_pairs_tested"] / max(ctr["points_in_bbox"], 1)
+            # bytes a kernel cannot avoid moving through HBM per call it runs in: k_integrate reads the frame and parks the survivors
+            # (16 + 16 B/pt: the 32 B of SURVEY 8(d)); k_update_cells reads the parked points back (16 B each; the dependants'
+            # records live in LDS and leave once per brick); k_buffer copies the buffered points into the log (16 + 16 B)
+            surv = ctr["points_in_bbox"] / max(ctr["points_presented"], 1)
             algo = {"k_integrate": ALGO_BYTES_PER_POINT * (n_frames * NPTS) / calls,
-                    "k_update_cells": 68.0 * ctr["dep_pairs_tested"] / calls,
-                    "k_buffer": 32.0 * ctr["points_buffered"] / calls}
+                    "k_update_cells": 16.0 * surv * (n_frames * NPTS) / calls,
+                    "k_buffer": 32.0 * ctr["points_buffered"] / max(per_kernel["k_buffer"][1], 1)}
             kernels = {}
             for name, (ms, n) in per_kernel.items():
                 avg_s = ms / 1e3 / max(n, 1)
@@ -367,7 +371,9 @@ def main():
                         k["traffic_GBps"] = round(tb / avg_s / 1e9, 2)
                         k["traffic_frac"] = round(tb / avg_s / 1e9 / HBM_PEAK_GBPS, 5)
                 kernels[name] = k
-            kernels["pairs_per_call"] = round(pairs_per_call)
+            upd_s = per_kernel["k_update_cells"][0] / 1e3
+            kernels["pairs_per_call"] = round(ctr["dep_pairs_tested"] / max(per_kernel["k_update_cells"][1], 1))
+            kernels["k_update_cells"]["Gpairs_per_s"] = round(ctr["dep_pairs_tested"] / upd_s / 1e9, 2) if upd_s > 0 else None
             kernels["pairs_per_surviving_point"] = round(d_bar, 3)
         # compute-side ceiling of the kernel that is not memory-bound (k_update_cells): what one (point, dependant) pair costs in VALU
         # lane-instructions against the pair loop's own minimum (projection, cylinder test, four fixed-point contributions: 48)

@@ -37,6 +37,12 @@ struct GridParams {
     // fixed-point scales (powers of two) of the order-free statistic sums, see stats.hpp
     float fs_scale, fss_scale, fd_scale, fdd_scale;
     float d2_max;  // largest f32 u with (double)sqrtf(u) < cyl_r: membership as one compare on the squared distance
+    // The reference's double compares of a float against the bbox / z-clip constants (grid.hpp:639-645, node.cpp:251-255), as float
+    // compares against the neighbouring float of each constant (found by the host at create): identical decisions for every float
+    // incl. NaN, six f64 compares and three conversions a point less, and 12 scalar registers less in k_integrate.
+    //   bb_hi[a] = smallest float >= max[a]:  (double)x >= max[a]  <=>  x >= bb_hi[a]        (same for zc_hi and "<")
+    //   bb_lo[a] = largest float  <= min[a]:  (double)x <= min[a]  <=>  x <= bb_lo[a]        (same for zc_lo and ">")
+    float bb_lo[3], bb_hi[3], zc_lo, zc_hi;
     // cell key = x << key_sx | y << key_sy | z with just enough bits per axis for 0..dim: ascending keys = the reference's
     // lexicographic (x,y,z) scan order, and the radix sorts run over key_bits bits (30 at 999^3) instead of 64
     uint32_t key_sy, key_sx, key_bits;
@@ -68,13 +74,12 @@ HFPF_HD F3 transform_point(const double* T, float x, float y, float z)
 }
 
 // node.cpp:251-255 z-clip in the camera frame: strict on both sides, NaN rejected.
-HFPF_HD bool zclip_pass(const GridParams& g, float z) { return ((double)z < g.zclip_max) && ((double)z > g.zclip_min); }
+HFPF_HD bool zclip_pass(const GridParams& g, float z) { return (z < g.zc_hi) && (z > g.zc_lo); }
 
 // grid.hpp:639-645 validPoints: float promoted to double in each compare; strict interior.
 HFPF_HD bool valid_point(const GridParams& g, F3 p)
 {
-    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
-    return !(x >= g.max[0] || y >= g.max[1] || z >= g.max[2] || x <= g.min[0] || y <= g.min[1] || z <= g.min[2]);
+    return !(p.x >= g.bb_hi[0] || p.y >= g.bb_hi[1] || p.z >= g.bb_hi[2] || p.x <= g.bb_lo[0] || p.y <= g.bb_lo[1] || p.z <= g.bb_lo[2]);
 }
 
 // grid.hpp:630-637 getVoxelCoords(Vector3f): floor((double(p) - min) / res) truncated to int.

@@ -163,6 +163,7 @@ class StagePool {
 };
 
 constexpr int kStageSlots = 8;
+constexpr size_t kXferChunk = 16u << 20;  // bytes per pinned chunk of extract's row download
 constexpr int kProbeFrames = 8;  // frames of a plan-less batch that go ahead of the rest to measure the per-brick demand
 constexpr int kFrameSlots = 8;  // uploads run ahead of the kernels by up to this many frames
 
@@ -193,7 +194,7 @@ struct hfpf_handle {
     uint32_t launch_seq = 0;  // integrate launches so far (rotates the log append regions)
     uint64_t frames_integrated = 0;
     bool normals_possible = false;   // a clean pass has run since the last clear (the host mirror of C_NORMALS may lag behind a no-wait pass)
-    bool small_sort = true;          // HFPF_SMALL_SORT=0: rocPRIM's default configuration for every size
+    bool stream_replay = true;       // HFPF_STREAM_REPLAY=0: every replay walks the chains
     bool clean_small_nowait = true;  // small clean passes run without a mid-pass read-back (HFPF_CLEAN_NOWAIT=0 restores it)
     uint64_t gate_done = 0; // occ_list entries already examined by a gate pass
     // A capacity / HIP / collective error in the middle of a clean pass leaves the tables half updated: the handle then refuses
@@ -224,6 +225,8 @@ struct hfpf_handle {
     hipEvent_t busy_ev = nullptr;         // recorded behind the last launch of the host-frame path
     bool busy_pending = false;
     bool update_cells = true;  // k_update_cells (cell-sorted form); HFPF_UPDATE_FORM=points: k_update (per-point form), A/B and tests
+    void* xfer_pin[2] = {nullptr, nullptr};  // pinned staging of extract's row download (two chunks in flight)
+    hipEvent_t xfer_ev[2] = {nullptr, nullptr};
     StagePool* stage_pool = nullptr;  // created by the first large bounce copy (HFPF_STAGE_THREADS helpers, default 4; 0 = none)
     int stage_threads = -1;
     int fslot_next = 0;
@@ -238,9 +241,12 @@ struct hfpf_handle {
     // two-pass (binned) dependant update (default; HFPF_FLAG_DIRECT_UPDATE switches it off)
     bool binned = false;
     bool bin_have_hist = false;   // bin_fill holds the demand of the previous launch
+    bool bin_from_probe = false;  // ... and that launch was the dry run of a session's first frames
     double bin_prev_points = 0;   // points presented by that launch (to scale the plan)
     uint64_t bin_pool = 0;        // entries in bin_pt
     uint64_t n_bricks_known = 0;  // bricks allocated at the last counter read-back
+    uint64_t n_bricks_before = 0; // ... and at the read-back before the count last changed
+    bool bin_spare = true;        // HFPF_BIN_SPARE=0: no bin regions for bricks the launch discovers
     float test_bin_scale = 1.f;   // tests only (HFPF_TEST_BIN_SCALE): shrinks the planned bin regions so that they overflow into the direct forms
     DevBuf bin_pt_buf, bin_rgb_buf;
 
@@ -349,14 +355,14 @@ __global__ void k_set_ctr3(unsigned long long* ctr, int i0, unsigned long long v
 // host spins on that number.  Against two blit copies + hipStreamSynchronize this saves ~20 us per read-back (the interrupt
 // and wake-up of the synchronize), and a clean pass needs two of them with the GPU idle meanwhile.  Stream order makes the
 // arrival of the number equivalent to a synchronize for everything enqueued before it.
-constexpr int kMboxLogWords = 4;  // words 0..3 of each 16-word region-counter line are in use
+constexpr int kMboxLogWords = 5;  // words 0..4 of each 16-word region-counter line are in use
 constexpr int kMboxWords = C_COUNT + kLogRegions * kMboxLogWords;  // + the sequence number in its own 64-byte line
 __global__ __launch_bounds__(256) void k_publish_counters(const unsigned long long* __restrict__ ctr, const unsigned long long* __restrict__ log_ctr,
                                                           unsigned long long* mbox, unsigned long long seq)
 {
     const unsigned i = threadIdx.x;
     if (i < (unsigned)C_COUNT) mbox[i] = ctr[i];
-    if (i < (unsigned)(kLogRegions * kMboxLogWords)) mbox[C_COUNT + i] = log_ctr[(i / kMboxLogWords) * 16 + (i % kMboxLogWords)];
+    for (unsigned w = i; w < (unsigned)(kLogRegions * kMboxLogWords); w += blockDim.x) mbox[C_COUNT + w] = log_ctr[(w / kMboxLogWords) * 16 + (w % kMboxLogWords)];
     __threadfence_system();
     __syncthreads();
     if (i == 0) __hip_atomic_store(&mbox[kMboxWords + 7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -406,7 +412,14 @@ int read_counters(hfpf_handle* h)
     }
     h->h_ctr[C_DEP_TESTED] += upd_tested;
     h->h_ctr[C_DEP_MEMBER] += upd_member;
-    h->n_bricks_known = std::min<uint64_t>(h->h_ctr[C_BRICKS], h->t.max_bricks);
+    unsigned long long single = 0;  // touched cells of the last dependant-table update that lie in single-run bricks (word 4)
+    for (int r = 0; r < kLogRegions; r++) single += h->h_log_ctr[r * 16 + 4];
+    h->h_ctr[C_TOUCHED_SINGLE] = single;
+    {
+        const uint64_t nbk = std::min<uint64_t>(h->h_ctr[C_BRICKS], h->t.max_bricks);
+        if (nbk != h->n_bricks_known) h->n_bricks_before = h->n_bricks_known;  // how fast the session discovers bricks (spare bin regions)
+        h->n_bricks_known = nbk;
+    }
     return HFPF_OK;
 }
 
@@ -462,6 +475,24 @@ int setup_params(hfpf_handle* h)
     }
     g.zclip_min = c.z_clip_min;
     g.zclip_max = c.z_clip_max;
+    {   // float neighbours of the double clip constants (geometry.hpp, GridParams::bb_lo): compares in f32 with identical decisions
+        auto float_at_or_above = [](double m) {
+            float f = (float)m;
+            if ((double)f < m) f = nextafterf(f, INFINITY);
+            return f;
+        };
+        auto float_at_or_below = [](double m) {
+            float f = (float)m;
+            if ((double)f > m) f = nextafterf(f, -INFINITY);
+            return f;
+        };
+        for (int a = 0; a < 3; a++) {
+            g.bb_hi[a] = float_at_or_above(g.max[a]);
+            g.bb_lo[a] = float_at_or_below(g.min[a]);
+        }
+        g.zc_hi = float_at_or_above(g.zclip_max);
+        g.zc_lo = float_at_or_below(g.zclip_min);
+    }
     g.cyl_r = c.cylinder_radius;
     g.ball_r = (float)c.ball_radius;
     g.K = c.K;
@@ -512,14 +543,15 @@ int reset_state(hfpf_handle* h)
     HIPCHK(h, hipMemsetAsync(t.bin_fill, 0, 2 * (t.max_bricks + 2) * 4, s));
     HIPCHK(h, hipMemsetAsync(t.bin_off, 0, 2 * (t.max_bricks + 2) * 4, s));
     HIPCHK(h, hipMemsetAsync(t.bin_capb, 0, 2 * (t.max_bricks + 2) * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.run_cnt, 0, (t.max_bricks + 2) * 4, s));
     h->bin_have_hist = false;
     h->normals_possible = false;
     h->pend_n = 0;
     h->pub_seq = 0;
-    h->upd_wide = false;
-    h->upd_miss_seen = h->upd_member_seen = 0;
+    h->upd_miss_seen = h->upd_member_seen = 0;  // (upd_wide stays: the next session on this handle fuses the same kind of scene)
     h->direct_linked = 0;
     h->n_bricks_known = 0;
+    h->n_bricks_before = 0;
     if (h->h_ctr) memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));  // host mirror follows the device counters
     h->dirty = false;
     for (int r = 0; r < kLogRegions; r++) h->n_linked[r] = 0;
@@ -588,7 +620,9 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(prereg_list, t.max_reg, 0, false);
     ALLOC(prechg_list, t.max_reg, 0, false);
     ALLOC(touched_list, h->max_touched, 0, false);
-    ALLOC(touched_old, h->max_touched, 0, false);
+    ALLOC(run_start, t.max_bricks + 2, 0, false);
+    ALLOC(run_len, t.max_bricks + 2, 0, false);
+    ALLOC(run_cnt, t.max_bricks + 2);
     ALLOC(cand_key, t.max_occ, 0, false);
     ALLOC(frame_vp, 3 * t.max_frames);
     ALLOC(ctr, C_COUNT);
@@ -604,24 +638,10 @@ int alloc_tables(hfpf_handle* h)
 
 // Cell keys: only the low GridParams::key_bits bits are significant (an all-ones sentinel still sorts behind every valid key:
 // a valid cell has x < dim <= 2^bits_x - 1, so its key is never all ones).
-// Small inputs (the candidate keys of a steady clean pass: a few 10^4): rocPRIM's default splits them into 1024-key blocks and
-// merges pairwise, nine launches of ~7 us for 40 k keys.  8192-key blocks (1024 threads x 8 keys) need one launch up to 8 k keys
-// and one block sort + three merges at 40 k.
-using SmallSortConfig = rocprim::radix_sort_config<rocprim::kernel_config<1024, 8>, rocprim::merge_sort_config<512, 1024, 8>, rocprim::default_config, 1024 * 1024>;
-constexpr uint64_t kSmallSortMax = 1ull << 17;  // (below rocPRIM's merge-path threshold: every merge pass is one launch)
-
 int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n)
 {
     const unsigned kb = h->g.key_bits;
     size_t bytes = 0;
-    if (n <= kSmallSortMax && h->small_sort) {
-        HIPCHK(h, rocprim::radix_sort_keys<SmallSortConfig>(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
-        int rc = scratch(h, h->sort_tmp, bytes);
-        if (rc) return rc;
-        bytes = h->sort_tmp.bytes;
-        HIPCHK(h, rocprim::radix_sort_keys<SmallSortConfig>(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, kb, h->stream));
-        return HFPF_OK;
-    }
     HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
@@ -638,17 +658,6 @@ int sort_keys_u32(hfpf_handle* h, uint32_t* in, uint32_t* out, uint64_t n, unsig
     if (rc) return rc;
     bytes = h->sort_tmp.bytes;
     HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, bits, h->stream));
-    return HFPF_OK;
-}
-
-int sort_pairs_u32(hfpf_handle* h, uint32_t* kin, uint32_t* kout, uint32_t* vin, uint32_t* vout, uint64_t n, unsigned bits)
-{
-    size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, bits, h->stream));
-    int rc = scratch(h, h->sort_tmp, bytes);
-    if (rc) return rc;
-    bytes = h->sort_tmp.bytes;
-    HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0, bits, h->stream));
     return HFPF_OK;
 }
 
@@ -779,17 +788,33 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         int rcp = read_counters(h);  // bricks the dry run claimed
         if (rcp) return rcp;
         h->bin_have_hist = true;
+        h->bin_from_probe = true;  // the plan of the launch below comes from a sample: more slack per region
         h->bin_prev_points = (double)n_points * kProbeFrames;
         launch_frames = n_frames;
         probe = 0;
     }
-    const uint32_t nb = (uint32_t)h->n_bricks_known;
+    const uint32_t nb_known = (uint32_t)h->n_bricks_known;
     // a plan = per-brick bin regions sized from the previous launch's demand; without one nothing is parked (direct forms)
-    const bool have_plan = bin && h->bin_have_hist && nb > 0;
+    const bool have_plan = bin && h->bin_have_hist && nb_known > 0;
+    // Bricks this launch may discover get spare regions of an average brick's size: as many as the session found between its last
+    // two counter read-backs (x2), i.e. half the known bricks right after the dry run and a few hundred in the steady state.
+    uint32_t spare = 0, spare_cap = 0;
+    if (have_plan && h->bin_spare) {
+        const uint64_t grown = h->n_bricks_known - std::min(h->n_bricks_known, h->n_bricks_before);
+        spare = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2 * grown, 256), std::max<uint64_t>(nb_known / 2, 256));
+        spare = (uint32_t)std::min<uint64_t>(spare, h->t.max_bricks - std::min<uint64_t>(h->t.max_bricks, nb_known));
+    }
+    const uint32_t nb = nb_known + spare;  // bricks the per-brick kernels of this call look at
     if (bin) {
         // pool for this launch's parked points (+25 % plan slack, +64 per brick)
         const uint64_t pts = (uint64_t)n_points * n_frames;
-        const uint64_t pool = 2 * (pts + pts / 3) + 128ull * (nb + 1);  // two regions per brick, each sized for the whole brick
+        uint64_t pool = 2 * (pts + pts / 3) + 128ull * (nb_known + 1);  // two regions per brick, each sized for the whole brick
+        if (spare) {  // an average brick's share of the batch, both regions, within what a 32-bit index still addresses
+            spare_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pts / std::max(1u, nb_known), 64), 1u << 15);
+            const uint64_t room = 0xFFFFFFFFull - std::min<uint64_t>(pool, 0xFFFFFFFFull);
+            if (2ull * spare * spare_cap > room) spare_cap = (uint32_t)(room / (2ull * spare));
+            pool += 2ull * spare * spare_cap;
+        }
         if (pool > 0xFFFFFFFFull) return fail(h, HFPF_ERR_BAD_ARG, "integrate: batch too large for the binned update (split the call)");
         if (h->bin_pool < pool) {
             int rc2 = scratch(h, h->bin_pt_buf, pool * sizeof(float4));
@@ -801,16 +826,19 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         h->t.bin_rgb = (uint32_t*)h->bin_rgb_buf.p;
         if (have_plan) {
             const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points)) * h->test_bin_scale;
-            const uint32_t n_regions = 2u * (nb + 1u);  // two per brick: cells with / without a normal
-            hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(n_regions, 256)), dim3(256), 0, h->stream, h->t, n_regions, scale);
+            const uint32_t n_regions = 2u * (nb_known + 1u);  // two per brick: cells with / without a normal
+            const uint32_t n_planned = 2u * (nb + 1u);        // ... and the spare ones behind them
+            hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(n_planned, 256)), dim3(256), 0, h->stream, h->t, n_regions, n_planned, spare_cap, scale,
+                               h->bin_from_probe ? 1.5f : 1.25f);
+            h->bin_from_probe = false;
             size_t bytes = 0;
-            HIPCHK(h, rocprim::exclusive_scan(nullptr, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_regions, rocprim::plus<uint32_t>(), h->stream));
+            HIPCHK(h, rocprim::exclusive_scan(nullptr, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_planned, rocprim::plus<uint32_t>(), h->stream));
             int rc2 = scratch(h, h->sort_tmp, bytes);
             if (rc2) return rc2;
             bytes = h->sort_tmp.bytes;
-            HIPCHK(h, rocprim::exclusive_scan(h->sort_tmp.p, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_regions, rocprim::plus<uint32_t>(), h->stream));
+            HIPCHK(h, rocprim::exclusive_scan(h->sort_tmp.p, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_planned, rocprim::plus<uint32_t>(), h->stream));
             const uint32_t all_regions = 2u * (uint32_t)(h->t.max_bricks + 2);
-            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(all_regions, 256)), dim3(256), 0, h->stream, h->t, n_regions, all_regions, h->bin_pool);
+            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(all_regions, 256)), dim3(256), 0, h->stream, h->t, n_planned, all_regions, h->bin_pool);
         } else {  // no plan yet: no region exists, every lane takes the direct forms, the demand is recorded
             HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
             HIPCHK(h, hipMemsetAsync(h->t.bin_capb, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
@@ -919,6 +947,7 @@ int resolve_timing(hfpf_handle* h)
         for (int k = 0; k < 3; k++) {
             float ms = 0.f;
             HIPCHK(h, hipEventElapsedTime(&ms, h->ev_detail[i + k], h->ev_detail[i + k + 1]));
+            if (ms < 0.02f) continue;  // the kernel did not run in this call (no dependants yet: no k_update_cells)
             h->t_detail_ms[k] += (double)ms;
             h->n_detail[k]++;
         }
@@ -1208,11 +1237,11 @@ int clean_locked(hfpf_handle* h, int pre_rc)
         HIPCHK(h, hipGetLastError());
         if (no_wait) {  // errors of this pass (capacity) surface at the next read-back and poison the handle there
             if (t.color)
-                hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(reg_ub * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)t.touched_list,
-                                   (const uint32_t*)t.touched_old, kCountOnDevice, n_normals);
+                hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(reg_ub * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)t.touched_list, 1u, 0u,
+                                   kCountOnDevice, n_normals);
             else
-                hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(reg_ub * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)t.touched_list,
-                                   (const uint32_t*)t.touched_old, kCountOnDevice, n_normals);
+                hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(reg_ub * kChains, 256)), dim3(256), 0, s, h->g, t, (const uint32_t*)t.touched_list, 1u, 0u,
+                                   kCountOnDevice, n_normals);
             HIPCHK(h, hipGetLastError());
             return HFPF_OK;
         }
@@ -1256,28 +1285,41 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     }
     // buffer replay of the cells that gained registrants in this pass (touched_list is still intact)
     if (inc_touched) {
-        // a 256-point tile appends consecutive log entries for neighbouring cells, so walking the cells in slot (brick-major)
-        // order lets adjacent lanes share cache lines of the log; a short list is not worth the sort's nine launches
-        const uint32_t* cells = t.touched_list;
-        const uint32_t* olds = full ? nullptr : t.touched_old;  // (a compacting rebuild leaves the lists in no particular order)
-        if (inc_touched >= (1ull << 18)) {
-            if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
-            unsigned slot_bits = 9;  // slot = brick * 512 + cell; the brick count is as of the read-back just above
-            while ((1ull << slot_bits) < (h->n_bricks_known + 2) * (uint64_t)kBrickCells && slot_bits < 32) slot_bits++;
-            if (olds) {
-                if ((rc = scratch(h, h->vals_b, inc_touched * 4))) return rc;
-                if ((rc = sort_pairs_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, t.touched_old, (uint32_t*)h->vals_b.p, inc_touched, slot_bits))) return rc;
-                olds = (const uint32_t*)h->vals_b.p;
-            } else if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched, slot_bits))) {
-                return rc;
-            }
-            cells = (const uint32_t*)h->vals_a.p;
+        const uint32_t use_marks = full ? 0u : 1u;  // (a compacting rebuild leaves no notes and the lists in no particular order)
+        // Bricks whose buffered points are ONE contiguous run of the log (the epoch was handed over in one integrate call, the
+        // brick is new in it) replay by streaming that run: worth its launch over every brick when enough of the touched cells
+        // lie in such bricks.  The chain walk takes the others.
+        const uint64_t single = full ? 0 : std::min<uint64_t>(h->h_ctr[C_TOUCHED_SINGLE], inc_touched);
+        const bool stream = !full && h->binned && h->stream_replay && single >= (1ull << 16);
+        if (stream) {
+            const uint32_t nbk = (uint32_t)h->n_bricks_known;
+#define HFPF_LAUNCH_STREAM(C, S) hipLaunchKernelGGL((k_update_cells<C, S.threads, S.cap, S.slots, S.desc, S.waves, true>), dim3(nbk), dim3(S.threads), 0, s, h->g, t, nbk)
+            const bool wide = h->upd_shape_forced >= 0 ? h->upd_shape_forced == 1 : h->upd_wide;  // the shape the dependant updates of this session take
+            if (t.color && wide) HFPF_LAUNCH_STREAM(true, kUpdWide);
+            else if (t.color) HFPF_LAUNCH_STREAM(true, kUpdDense);
+            else if (wide) HFPF_LAUNCH_STREAM(false, kUpdWide);
+            else HFPF_LAUNCH_STREAM(false, kUpdDense);
+#undef HFPF_LAUNCH_STREAM
+            HIPCHK(h, hipGetLastError());
         }
-        if (t.color)
-            hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, olds, inc_touched, n_normals);
-        else
-            hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, olds, inc_touched, n_normals);
-        HIPCHK(h, hipGetLastError());
+        const uint64_t walked = stream ? inc_touched - single : inc_touched;
+        if (walked) {
+            // a 256-point tile appends consecutive log entries for neighbouring cells, so walking the cells in slot (brick-major)
+            // order lets adjacent lanes share cache lines of the log; a short list is not worth the sort's launches
+            const uint32_t* cells = t.touched_list;
+            if (walked >= (1ull << 18)) {
+                if ((rc = scratch(h, h->vals_a, inc_touched * 4))) return rc;
+                unsigned slot_bits = 9;  // slot = brick * 512 + cell; the brick count is as of the read-back just above
+                while ((1ull << slot_bits) < (h->n_bricks_known + 2) * (uint64_t)kBrickCells && slot_bits < 32) slot_bits++;
+                if ((rc = sort_keys_u32(h, t.touched_list, (uint32_t*)h->vals_a.p, inc_touched, slot_bits))) return rc;
+                cells = (const uint32_t*)h->vals_a.p;
+            }
+            if (t.color)
+                hipLaunchKernelGGL(k_replay<true>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, use_marks, stream ? 1u : 0u, inc_touched, n_normals);
+            else
+                hipLaunchKernelGGL(k_replay<false>, dim3(blocks_for(inc_touched * kChains, 256)), dim3(256), 0, s, h->g, t, cells, use_marks, stream ? 1u : 0u, inc_touched, n_normals);
+            HIPCHK(h, hipGetLastError());
+        }
     }
     return HFPF_OK;
 }
@@ -1347,7 +1389,8 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         h->update_cells = !(uf && uf[0] == 'p');
         if (const char* hb = getenv("HFPF_HOST_BATCH")) h->host_batch = std::max(1, std::min(atoi(hb), kFrameSlots));
         if (const char* us = getenv("HFPF_UPD_SHAPE")) h->upd_shape_forced = std::max(0, std::min(atoi(us), 1));
-        if (const char* ss = getenv("HFPF_SMALL_SORT")) h->small_sort = ss[0] != '0';
+        if (const char* sp = getenv("HFPF_BIN_SPARE")) h->bin_spare = sp[0] != '0';
+        if (const char* sr = getenv("HFPF_STREAM_REPLAY")) h->stream_replay = sr[0] != '0';
         if (const char* nw = getenv("HFPF_CLEAN_NOWAIT")) h->clean_small_nowait = nw[0] != '0';
         if (const char* bs = getenv("HFPF_TEST_BIN_SCALE")) h->test_bin_scale = std::max(0.f, std::min(1.f, (float)atof(bs)));
         const char* mb = getenv("HFPF_MAILBOX");
@@ -1380,6 +1423,14 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
             h->bin_pool = pool;
         }
     }
+    for (int k = 0; k < 2; k++) {  // (a failure here only costs speed: extract then copies straight into pageable memory)
+        if (hipHostMalloc(&h->xfer_pin[k], kXferChunk, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&h->xfer_ev[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->xfer_pin[0]) (void)hipHostFree(h->xfer_pin[0]);
+            h->xfer_pin[0] = nullptr;
+            break;
+        }
+    }
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "sync after init: %s", hipGetErrorString(e)));
     *out = h;
     return HFPF_OK;
@@ -1407,6 +1458,10 @@ int hfpf_destroy(hfpf_handle* h)
     }
     delete h->stage_pool;
     h->stage_pool = nullptr;
+    for (int k = 0; k < 2; k++) {
+        if (h->xfer_pin[k]) (void)hipHostFree(h->xfer_pin[k]);
+        if (h->xfer_ev[k]) (void)hipEventDestroy(h->xfer_ev[k]);
+    }
     for (auto& f : h->fslot) {
         if (f.h) (void)hipHostFree(f.h);
         if (f.done) (void)hipEventDestroy(f.done);
@@ -1455,6 +1510,25 @@ int hfpf_integrate_device(hfpf_handle* h, const void* dev_base, uint32_t n_frame
     if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     if (int rc = check_usable(h)) return rc;
     return integrate_device_locked(h, dev_base, n_frames, frame_stride, n_points, point_step, off_x, off_y, off_z, off_rgb, poses, frame_ids);
+}
+
+// Large host-to-host copies (the bounce copy of hfpf_integrate, the row download of extract) are split over the caller and the
+// helper threads of the handle's StagePool (HFPF_STAGE_THREADS, default half the process's cores - 1, at most 7; 0 = none).
+static void host_copy(hfpf_handle* h, void* dst, const void* src, size_t bytes)
+{
+    if (h->stage_threads < 0) {
+        const char* e = getenv("HFPF_STAGE_THREADS");
+        int cores = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cores = std::min(cores > 0 ? cores : 1 << 20, CPU_COUNT(&set));  // the process's share
+        h->stage_threads = e ? std::max(0, std::min(atoi(e), 15)) : std::max(0, std::min(7, cores / 2 - 1));
+    }
+    if (h->stage_threads > 0 && bytes >= (1u << 20)) {
+        if (!h->stage_pool) h->stage_pool = new StagePool(h->stage_threads);
+        h->stage_pool->copy(dst, src, bytes);
+    } else {
+        stream_copy((char*)dst, (const char*)src, bytes);
+    }
 }
 
 // Hand the uploaded-but-not-launched host frames to the kernels: one integrate launch for the batch.
@@ -1542,19 +1616,7 @@ static int integrate_host_locked(hfpf_handle* h, const void* base, bool bounce, 
             f.cap_h = h->ring_cap;
         }
         // the caller's buffer is free again when this call returns
-        if (h->stage_threads < 0) {
-            const char* e = getenv("HFPF_STAGE_THREADS");
-            int cores = (int)std::thread::hardware_concurrency();
-            cpu_set_t set;
-            if (sched_getaffinity(0, sizeof set, &set) == 0) cores = std::min(cores > 0 ? cores : 1 << 20, CPU_COUNT(&set));  // the process's share
-            h->stage_threads = e ? std::max(0, std::min(atoi(e), 15)) : std::max(0, std::min(7, cores / 2 - 1));
-        }
-        if (h->stage_threads > 0 && bytes >= (1u << 20)) {
-            if (!h->stage_pool) h->stage_pool = new StagePool(h->stage_threads);
-            h->stage_pool->copy(f.h, base, bytes);
-        } else {
-            stream_copy((char*)f.h, (const char*)base, bytes);
-        }
+        host_copy(h, f.h, base, bytes);
         src = f.h;
     }
     HIPCHK(h, hipMemcpyAsync((char*)h->ring_d + (size_t)slot * h->ring_cap, src, bytes, hipMemcpyHostToDevice, h->copy_stream));
@@ -1691,8 +1753,32 @@ static int extract_locked(hfpf_handle* h, const unsigned long long* stats, const
     HIPCHK(h, hipGetLastError());
     hfpf_row* host = (hfpf_row*)malloc(nr * sizeof(hfpf_row));
     if (!host) return fail(h, HFPF_ERR_CAPACITY, "extract: host allocation of %llu rows failed", (unsigned long long)nr);
-    hipError_t e = hipMemcpyAsync(host, h->rows_dev.p, nr * sizeof(Row), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    // The rows go to pageable memory the caller will free(): a direct device-to-pageable copy runs at ~10 GB/s through the
+    // runtime's own staging.  Two pinned 16 MB buffers instead: chunk i+1 crosses the link while chunk i is copied out by the
+    // caller and the helper threads.
+    const size_t total = nr * sizeof(Row);
+    hipError_t e = hipSuccess;
+    if (h->xfer_pin[0] && total >= 2 * kXferChunk) {
+        const size_t n_chunks = (total + kXferChunk - 1) / kXferChunk;
+        auto issue = [&](size_t i) -> hipError_t {
+            const size_t off = i * kXferChunk, len = std::min(kXferChunk, total - off);
+            const hipError_t r = hipMemcpyAsync(h->xfer_pin[i & 1], (const char*)h->rows_dev.p + off, len, hipMemcpyDeviceToHost, h->stream);
+            return r != hipSuccess ? r : hipEventRecord(h->xfer_ev[i & 1], h->stream);
+        };
+        e = issue(0);
+        if (e == hipSuccess && n_chunks > 1) e = issue(1);
+        for (size_t i = 0; i < n_chunks && e == hipSuccess; i++) {
+            const size_t off = i * kXferChunk, len = std::min(kXferChunk, total - off);
+            e = hipEventSynchronize(h->xfer_ev[i & 1]);
+            if (e != hipSuccess) break;
+            host_copy(h, (char*)host + off, h->xfer_pin[i & 1], len);
+            if (i + 2 < n_chunks) e = issue(i + 2);  // this buffer is free again
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    } else {
+        e = hipMemcpyAsync(host, h->rows_dev.p, total, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
     if (e != hipSuccess) {
         free(host);
         return fail(h, HFPF_ERR_HIP, "extract copy: %s", hipGetErrorString(e));
@@ -2071,6 +2157,8 @@ int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)
     out->clean_passes = h->clean_passes;
     out->device_bytes = h->device_bytes;
     out->replay_members = c[C_REPLAY_MEMBER];
+    out->points_direct = c[C_BUFFERED];
+    out->table_misses = c[C_TABLE_MISS];
     return HFPF_OK;
 }
 

@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridPar
                 // atomic) and no pass over the log is needed afterwards.  Direct form (every point comes this way): .w carries the
                 // marked slot until k_link_log chains the entries of the epoch in one go.
                 uint32_t link = slot | kLogUnlinked;
-                if (BIN) link = atomicExch(&t.buf_head[(uint64_t)slot * kLogChains + ((uint32_t)e & (kLogChains - 1))], (uint32_t)e);
+                if (BIN) {
+                    link = atomicExch(&t.buf_head[(uint64_t)slot * kLogChains + ((uint32_t)e & (kLogChains - 1))], (uint32_t)e);
+                    if (!(t.run_cnt[b] & 0x100u)) atomicOr(&t.run_cnt[b], 0x100u);  // an entry outside the brick's runs: its replay walks the chains
+                }
                 t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(link));
                 if (COLOR) t.log_rgb[e] = rgb;
             } else {
@@ -554,9 +557,6 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
 #ifndef HFPF_UPD2_CHUNK
 #define HFPF_UPD2_CHUNK 8  // points of a cell one work item takes
 #endif
-#ifndef HFPF_UPD2_ABL
-#define HFPF_UPD2_ABL 0  // TIMING-ONLY ablations (the results are wrong): 1 no table insert, 2 no pair loop, 3 no items, 4 loads only
-#endif
 constexpr int kUpd2Chunk = HFPF_UPD2_CHUNK;
 static_assert(kUpd2Chunk >= 1 && kUpd2Chunk <= 15, "k_update_cells: int32 item sums hold 15 contributions");
 constexpr uint32_t kUpd2NoDesc = ~0u;
@@ -603,41 +603,60 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 #endif
 }
 
-template <bool COLOR, int THREADS, int CAP, int SLOTS, int DESC, int WAVES>
+// REPLAY = true is the buffer replay of a clean pass (grid.hpp:418-440) for bricks whose buffered points form ONE contiguous run of
+// the point log (Tables::run_*): the same kernel with the run as its input instead of the bin -- the cell of a logged point is
+// recomputed from its coordinates, exactly as k_integrate indexed it -- and with every cell's dependant list cut down to the
+// registrants of the running pass (the note k_depinc_fill left in the cell's scratch word, cleared here).  Coalesced reads of the
+// run instead of one dependent 16-byte chain hop per point.
+template <bool COLOR, int THREADS, int CAP, int SLOTS, int DESC, int WAVES, bool REPLAY = false>
 __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParams g, const Tables t, const uint32_t n_bricks)
 {
-    static_assert(THREADS == 256 || THREADS == 512 || THREADS == 1024, "k_update_cells: one or two cells per scanning thread");
+    static_assert(THREADS == kBrickCells, "k_update_cells: thread t owns cell t");
     static_assert(CAP % THREADS == 0 && CAP <= 4095 && (CAP + kUpd2Chunk - 1) / kUpd2Chunk <= 256, "k_update_cells: cell record holds 12-bit positions, descriptor 8-bit chunks");
     constexpr int kUpd2Threads = THREADS, kUpd2Cap = CAP, kUpd2Slots = SLOTS, kUpd2Desc = DESC;
     auto upd2_hash = [](uint32_t sid) -> uint32_t { return __umulhi(sid * 2654435761u, (uint32_t)SLOTS); };
     constexpr int W = COLOR ? 8 : kStatUsed;
-    constexpr uint32_t T = kUpd2Threads, NW = T / 64, CPT = T >= kBrickCells ? 1 : kBrickCells / T, PER = kUpd2Cap / T, CH = kUpd2Chunk;
+    constexpr uint32_t T = kUpd2Threads, CPT = 1, PER = kUpd2Cap / T, CH = kUpd2Chunk;
     __shared__ float s_px[kUpd2Cap], s_py[kUpd2Cap], s_pz[kUpd2Cap];  // sorted points, one array per coordinate (12 bytes a point)
     __shared__ uint32_t s_rgb[COLOR ? kUpd2Cap : 1];
     __shared__ uint32_t s_cnt[kBrickCells];
     __shared__ uint64_t s_pack[kBrickCells];       // per cell and round: dependant-list offset (32) | first sorted position (12) | points (12)
     __shared__ uint32_t s_items[kBrickCells + 1];  // first work item of each cell (only the search path and the total read it)
     __shared__ uint32_t s_desc[kUpd2Desc];         // per work item: cell (9) | chunk (8) | entry (15)
-    __shared__ uint32_t s_wsum[2][NW];
+    __shared__ uint32_t s_wsum[2][T / 64];
     __shared__ uint32_t keys[kUpd2Slots];
     __shared__ unsigned long long vals[kUpd2Slots * W];
     __shared__ unsigned int blk_ctr[3];
     const uint32_t b = blockIdx.x + 1;
     if (b > n_bricks) return;
-    const uint32_t fill_a = min(t.bin_fill[2 * b], t.bin_capb[2 * b]), fill_b = min(t.bin_fill[2 * b + 1], t.bin_capb[2 * b + 1]);
+    if (REPLAY && t.run_cnt[b] != 1u) return;  // block-uniform: several runs or stray entries -- the chain walk replays this brick
+    const uint32_t fill_a = REPLAY ? t.run_len[b] : min(t.bin_fill[2 * b], t.bin_capb[2 * b]);
+    const uint32_t fill_b = REPLAY ? 0u : min(t.bin_fill[2 * b + 1], t.bin_capb[2 * b + 1]);
     const uint32_t fill = fill_a + fill_b;
     if (fill == 0) return;  // block-uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t first_a = t.bin_off[2 * b], first_b = t.bin_off[2 * b + 1];
+    const uint64_t first_a = REPLAY ? t.run_start[b] : t.bin_off[2 * b], first_b = REPLAY ? 0u : t.bin_off[2 * b + 1];
     auto entry = [&](uint32_t i) -> uint64_t { return i < fill_a ? first_a + i : first_b + (i - fill_a); };
     const bool scanner = tid < (uint32_t)kBrickCells / CPT;  // wave-uniform: the threads that own cells
     uint32_t own_cnt[CPT], own_off[CPT];
+    bool any_note = false;
 #pragma unroll
     for (uint32_t k = 0; k < CPT; k++) {
-        const uint64_t info = scanner ? t.info[(uint64_t)b * kBrickCells + tid * CPT + k] : 0ull;
+        const uint64_t cslot = (uint64_t)b * kBrickCells + tid * CPT + k;
+        const uint64_t info = scanner ? t.info[cslot] : 0ull;
         own_cnt[k] = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
         own_off[k] = (uint32_t)(info >> kDepOffShift);  // dep[] stays below 2^32 entries (host-checked)
+        if (REPLAY) {  // only the registrants of the running pass: the entries behind the old list length
+            const uint32_t note = scanner ? t.dep_tmp[cslot] : 0u;
+            const bool noted = (note & kTouchedMark) != 0;
+            const uint32_t old_len = noted ? min(note & kDepOldMax, own_cnt[k]) : own_cnt[k];
+            own_off[k] += old_len;
+            own_cnt[k] -= old_len;
+            if (noted) t.dep_tmp[cslot] = 0;
+            any_note = any_note || noted;
+        }
     }
+    if (REPLAY && !__syncthreads_or(any_note ? 1 : 0)) return;  // block-uniform: no cell of this brick gained a registrant
     for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += T) s_cnt[i] = 0;
     for (uint32_t i = tid; i < (uint32_t)kUpd2Slots; i += T) keys[i] = 0;
     for (uint32_t i = tid; i < (uint32_t)(kUpd2Slots * W); i += T) vals[i] = 0;
@@ -655,8 +674,16 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
             col[k] = 0;
             pt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < fill) {
-                pt[k] = t.bin_pt[entry(i)];
-                if (COLOR) col[k] = t.bin_rgb[entry(i)];
+                if (REPLAY) {
+                    pt[k] = t.log_pt[entry(i)];
+                    if (COLOR) col[k] = t.log_rgb[entry(i)];
+                    int32_t ix, iy, iz;  // the cell the point was buffered under (grid.hpp:630-637 on the same f32 point)
+                    voxel_coords(g, F3{pt[k].x, pt[k].y, pt[k].z}, ix, iy, iz);
+                    pt[k].w = __uint_as_float(local_index(ix, iy, iz));
+                } else {
+                    pt[k] = t.bin_pt[entry(i)];
+                    if (COLOR) col[k] = t.bin_rgb[entry(i)];
+                }
             }
         }
     };
@@ -697,15 +724,6 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
     };
     load_round(0);
     __syncthreads();
-#if HFPF_UPD2_ABL == 4
-    {
-        uint32_t keep = own_cnt[0] ^ own_off[0];
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) keep ^= __float_as_uint(pt[k].x) ^ __float_as_uint(pt[k].w);
-        if (keep == 0x12345u) atomicAdd(&blk_ctr[0], 1u);
-        return;
-    }
-#endif
     for (uint32_t r0 = 0; r0 < fill; r0 += (uint32_t)kUpd2Cap) {  // block-uniform trip count
         const uint32_t n_round = min((uint32_t)kUpd2Cap, fill - r0);
         // 1. rank within the cell from the histogram's returning atomic
@@ -718,7 +736,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
         __syncthreads();
         // 2. exclusive scans over the cells: sorted position of the cell's first point, index of its first work item
         uint32_t n[CPT], it[CPT], sum_n = 0, sum_it = 0, inc_n = 0, inc_it = 0;
-        if (scanner) {
+        {
 #pragma unroll
             for (uint32_t k = 0; k < CPT; k++) {
                 const uint32_t c = tid * CPT + k;
@@ -734,7 +752,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
         }
         __syncthreads();
         // 3. cell records and item descriptors
-        if (scanner) {
+        {
             uint32_t pre_n = inc_n - sum_n, pre_it = inc_it - sum_it;
             for (uint32_t w2 = 0; w2 < wave; w2++) pre_n += s_wsum[0][w2], pre_it += s_wsum[1][w2];
 #pragma unroll
@@ -755,7 +773,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
             if (tid == (uint32_t)kBrickCells / CPT - 1) s_items[kBrickCells] = pre_it;
         }
         __syncthreads();
-        const uint32_t total = HFPF_UPD2_ABL == 3 ? 0u : s_items[kBrickCells];
+        const uint32_t total = s_items[kBrickCells];
         Item nxt;
         nxt.first = nxt.p_lo = nxt.p_hi = 0;
         nxt.e0 = nxt.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -780,9 +798,6 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
             const F3 la = F3{cur.e0.y, cur.e0.z, cur.e0.w}, lab = F3{cur.e1.x, cur.e1.y, cur.e1.z};
             const LineDiv dv = line_div_of(cur.e1.w);
             int32_t a_n = 0, a_s = 0, a_ss = 0, a_d = 0, a_dd = 0, a_r = 0, a_g = 0, a_b = 0;
-#if HFPF_UPD2_ABL == 2
-            c_member += (__float_as_uint(cur.e0.x) ^ __float_as_uint(cur.e1.w) ^ __float_as_uint(la.x) ^ __float_as_uint(lab.x) ^ __float_as_uint(dv.r)) & 1u;
-#else
             F3 qn = F3{0.f, 0.f, 0.f};  // the next point of the run is read while this one is tested
             if (cur.p_lo < cur.p_hi) qn = F3{s_px[cur.first + cur.p_lo], s_py[cur.first + cur.p_lo], s_pz[cur.first + cur.p_lo]};
             for (uint32_t pi = cur.p_lo; pi < cur.p_hi; pi++) {
@@ -803,13 +818,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
                     a_b += (int32_t)(rgb & 255u);
                 }
             }
-#endif
             c_tested += cur.p_hi - cur.p_lo;
             c_member += (uint32_t)a_n;
-#if HFPF_UPD2_ABL == 1
-            c_member += (uint32_t)(a_s ^ a_ss ^ a_d ^ a_dd ^ a_r ^ a_g ^ a_b) & 1u;
-            continue;
-#endif
             if (a_n == 0) continue;
             const uint32_t sid = __float_as_uint(cur.e0.x);
             uint32_t h = upd2_hash(sid);
@@ -861,8 +871,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
         if (c_miss) atomicAdd(&blk_ctr[2], c_miss);
     }
     __syncthreads();
-    if (tid < 2 && blk_ctr[tid])
+    if (REPLAY) {  // members found at replay time are counted apart (word 1 of the striped lines, like k_replay)
+        if (tid == 1 && blk_ctr[1]) atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 1], (unsigned long long)blk_ctr[1]);
+    } else if (tid < 2 && blk_ctr[tid]) {
         atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
+    }
     if (tid == 2 && blk_ctr[2]) atomicAdd(&t.ctr[C_TABLE_MISS], (unsigned long long)blk_ctr[2]);  // rare by construction
 }
 
@@ -890,7 +903,13 @@ __global__ __launch_bounds__(256) void k_buffer(const GridParams g, const Tables
     const uint64_t first = t.bin_off[2 * b + 1];
     const uint32_t region = b & (kLogRegions - 1);
     const bool in_lds = n_buf >= kBufLdsMin;  // block-uniform
-    if (tid == 0) s_base = atomicAdd(&t.log_ctr[region * 16], (unsigned long long)n_buf);
+    if (tid == 0) {
+        s_base = atomicAdd(&t.log_ctr[region * 16], (unsigned long long)n_buf);
+        const bool fits = s_base + n_buf <= t.log_region_cap;
+        t.run_start[b] = (uint32_t)((uint64_t)region * t.log_region_cap + s_base + 1);
+        t.run_len[b] = n_buf;
+        t.run_cnt[b] += fits ? 1u : 0x100u;  // (one workgroup per brick and launch: no other writer)
+    }
     if (in_lds) {
         for (uint32_t i = tid; i < (uint32_t)(kBrickCells * kChains); i += 256) s_head[i] = t.buf_head[(uint64_t)b * kBrickCells * kChains + i];
         for (uint32_t i = tid; i < (uint32_t)kBrickCells; i += 256) s_minfid[i] = kNoFrame;
@@ -933,18 +952,25 @@ __global__ __launch_bounds__(256) void k_buffer(const GridParams g, const Tables
     }
 }
 
-// Plan the bin regions of the next launch from the demand of the previous one: cap = demand * scale * 1.25 + 64, where the
+// Plan the bin regions of the next launch from the demand of the previous one: cap = demand * scale * slack + 64 (slack 1.25; 1.5
+// when the demand is the dry run's sample of 8 frames, whose per-brick counts scatter more), where the
 // demand is the BRICK's (both regions): a clean pass between two launches moves cells from "no normal" to "normal", so either
 // region must be able to take all of the brick's points.  n_regions = 2 * (bricks + 1); regions 0 and 1 belong to the null
 // brick and stay empty.
-__global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_regions, const float scale)
+// Regions [n_regions, n_planned) belong to brick ids the host has not seen yet: ids are handed out in order, so the next bricks a
+// launch discovers find a region of `spare_cap` entries waiting (without one all their points take the direct forms inside
+// k_integrate -- in the first epoch of a session that was one point in N).
+__global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_regions, const uint32_t n_planned, const uint32_t spare_cap, const float scale,
+                                                  const float slack)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_regions) return;
+    if (r >= n_planned) return;
     uint32_t cap = 0;
-    if (r >= 2) {
+    if (r >= n_regions) {
+        cap = spare_cap;
+    } else if (r >= 2) {
         const uint32_t demand = t.bin_fill[r & ~1u] + t.bin_fill[r | 1u];
-        if (demand) cap = (uint32_t)fminf((float)demand * scale * 1.25f, 2.0e9f) + 64u;  // (saturated: a float above 2^32 does not convert)
+        if (demand) cap = (uint32_t)fminf((float)demand * scale * slack, 2.0e9f) + 64u;  // (saturated: a float above 2^32 does not convert)
     }
     t.bin_capb[r] = cap;
 }
@@ -958,7 +984,8 @@ __global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= all_regions) return;
-    if (r < n_regions && (uint64_t)t.bin_off[r] + t.bin_capb[r] > pool) t.bin_capb[r] = 0;
+    // (regions behind the planned ones are off: an earlier launch may have planned more spare regions than this one)
+    if (r >= n_regions || (uint64_t)t.bin_off[r] + t.bin_capb[r] > pool) t.bin_capb[r] = 0;
     t.bin_fill[r] = 0;
 }
 
@@ -1111,6 +1138,7 @@ __global__ __launch_bounds__(256) void k_clean_begin(const Tables t, const uint6
         t.ctr[C_PRECHG] = 0;
         t.ctr[C_TOUCHED] = 0;
     }
+    if (i < (uint64_t)kLogRegions) t.log_ctr[i * 16 + 4] = 0;  // touched cells in single-run bricks (k_depinc_offsets)
 }
 
 // K4: one thread per candidate, in ascending key order; record id = base + rank + 1.
@@ -1271,12 +1299,13 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
 // Random 16-byte chain reads are the cost (sector amplification makes them HBM-bound), so reading each entry once
 // instead of once per registrant is the lever.  Runs after the dependant table has been updated.
 template <bool COLOR>
-__global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint32_t* __restrict__ olds,
-                                                const uint64_t n_touched_arg, const uint64_t base)
+__global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables t, const uint32_t* __restrict__ cells, const uint32_t use_marks,
+                                                const uint32_t skip_single, const uint64_t n_touched_arg, const uint64_t base)
 {
-    // olds (may be null): per touched cell, the length its dependant list had before this pass.  The incremental update appends, so
-    // the registrants of this pass are the entries behind that position and the walk over the older ones -- one dependent 32-byte
-    // read each -- is skipped.  Without it (compacting rebuild: any order) every entry is looked at and filtered by record id.
+    // use_marks: the incremental update left kTouchedMark | old list length in the cell's scratch word.  It appends, so the
+    // registrants of this pass are the entries behind that position and the walk over the older ones -- one dependent 32-byte read
+    // each -- is skipped; the note is cleared here.  Without marks (compacting rebuild: any order) every entry is looked at and
+    // filtered by record id.  skip_single: cells of single-run bricks are left (with their note) to the streaming replay.
     __shared__ unsigned long long queue[4][kQueueRows * kQueueStride];
     unsigned long long* q = queue[threadIdx.x >> 6];
     const uint64_t n_touched = n_touched_arg == kCountOnDevice ? (uint64_t)t.ctr[C_TOUCHED] : n_touched_arg;
@@ -1285,8 +1314,12 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     const uint32_t sub = (uint32_t)(gid % kChains);  // which of the cell's interleaved chains this lane walks
     uint32_t slot = 0, cnt = 0, head = 0;
     uint64_t off = 0;
-    if (j < n_touched) {
+    bool mine = j < n_touched;
+    if (mine) {
         slot = cells[j];  // touched cells in slot (brick-major) order: adjacent lanes walk chains that share cache lines
+        if (skip_single && t.run_cnt[slot >> 9] == 1u) mine = false;  // (with its note) left to the streaming replay
+    }
+    if (mine) {
         const uint64_t info = t.info[slot];
         cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
         off = info >> kDepOffShift;
@@ -1300,7 +1333,13 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     }
     uint32_t replayed = 0;
     uint32_t next = 0;  // next dependant entry to look at
-    if (olds && j < n_touched) next = min(olds[j], cnt);
+    if (use_marks && mine) {
+        const uint32_t m = t.dep_tmp[slot];  // the four lanes of a cell read it in the same instruction, then lane 0 clears it
+        if (m & kTouchedMark) {
+            next = min(m & kDepOldMax, cnt);
+            if (sub == 0) t.dep_tmp[slot] = 0;
+        }
+    }
     // wave-uniform outer loop: every lane keeps calling the flush helper until all lanes are done
     while (__ballot(next < cnt) != 0) {
         constexpr int B = HFPF_REPLAY_B;
@@ -1515,6 +1554,7 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
     }
     __shared__ TileReserveScratch<kListTiles> trs;
     unsigned long long off_[kListTiles];
+    uint32_t n_single = 0;
     block_reserve_tiles<kListTiles>(&t.ctr[C_DEP], new_cnt_, off_, trs);  // one atomic per workgroup; lists of neighbouring cells stay adjacent
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
@@ -1523,18 +1563,26 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
         const uint32_t slot = slot_[tt], old_cnt = old_cnt_[tt], new_cnt = new_cnt_[tt];
         const uint64_t info = info_[tt], old_off = info >> kDepOffShift;
         const unsigned long long off = off_[tt];
-        if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask) {  // host falls back to a full (compacting) rebuild
-            atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
-            t.dep_tmp[slot] = 0x80000000u;  // poison: k_depinc_fill skips this cell
-            t.touched_old[j] = 0;
+        if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask || old_cnt > kDepOldMax) {  // host falls back to a full (compacting) rebuild
+            atomicOr(&t.ctr[C_ERR], (unsigned long long)((new_cnt > kDepCntMask || old_cnt > kDepOldMax) ? E_DEPCNT : E_DEP));
+            t.dep_tmp[slot] = kDepPoison;  // k_depinc_fill skips this cell
             continue;
         }
+        n_single += t.run_cnt[slot >> 9] == 1u ? 1u : 0u;
         for (uint32_t k = 0; k < old_cnt; k++) t.dep[off + k] = t.dep[old_off + k];
         t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
         if (old_cnt == 0 && new_cnt) set_dep_flag(t, slot);
-        t.dep_tmp[slot] = old_cnt;     // append cursor
-        t.touched_old[j] = old_cnt;    // the entries behind it are this pass's registrants: where k_replay starts reading
+        t.dep_tmp[slot] = (old_cnt << 16) | old_cnt;  // old length | append cursor
     }
+    // cells in single-run bricks, for the host's choice of replay form: word 4 of the striped counter lines, one atomic per workgroup
+    __shared__ unsigned int s_single;
+    if (threadIdx.x == 0) s_single = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_single += __shfl_down(n_single, o);
+    if ((threadIdx.x & 63u) == 0 && n_single) atomicAdd(&s_single, n_single);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_single) atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 4], (unsigned long long)s_single);
 }
 
 __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg)
@@ -1543,13 +1591,14 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
     const uint64_t j = reg_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_reg) return;
     const uint2 r = t.reg_occ[j];
-    const uint32_t k = atomicAdd(&t.dep_tmp[r.x], 1u);
-    if (k & 0x80000000u) return;
+    const uint32_t v = atomicAdd(&t.dep_tmp[r.x], 1u);
+    if (v & kDepPoison) return;
+    const uint32_t k = v & 0xFFFFu;
     const uint64_t info = t.info[r.x];
     t.dep[(info >> kDepOffShift) + k] = make_dep_entry(t, r.y);
-    // exactly (new length - old length) tickets are drawn per cell: whoever draws the last one leaves the scratch word at zero
-    // for the next pass (k_dep_reset only runs in front of a compacting rebuild now)
-    if (k + 1 == (uint32_t)((info >> kDepCntShift) & kDepCntMask)) t.dep_tmp[r.x] = 0;
+    // exactly (new length - old length) tickets are drawn per cell: whoever draws the last one turns the cursor word into the
+    // note for the replay -- this cell gained registrants, they sit behind entry `old length` -- which the replay clears again
+    if (k + 1 == (uint32_t)((info >> kDepCntShift) & kDepCntMask)) t.dep_tmp[r.x] = kTouchedMark | ((v >> 16) & kDepOldMax);
 }
 
 // Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).

@@ -41,6 +41,10 @@ constexpr uint32_t kNoFrame = 0xFFFFFFFFu;
 
 // info word (bit 0 is unused: occupancy lives in the brick's occ_mask alone, one returning atomic per first touch)
 constexpr uint64_t kNormal = 2ull;
+// dep_tmp (per slot, scratch of the dependant-table update): during the incremental fill  old length << 16 | append cursor;
+// afterwards, until the replay has taken note,  kTouchedMark | old length  (the entries behind `old length` are the registrants
+// of the running pass); kDepPoison marks a cell the update had to give up on.  Zero between passes.
+constexpr uint32_t kTouchedMark = 0x40000000u, kDepPoison = 0x80000000u, kDepOldMax = 0x7FFFu;
 constexpr int kDepCntShift = 2;
 constexpr uint64_t kDepCntMask = 0xFFFFull;
 constexpr int kDepOffShift = 18;
@@ -67,6 +71,7 @@ enum Ctr : int {
     C_REPLAY_MEMBER, // buffered points that fell inside a cylinder during clean-time replay
     C_PEND,         // occupied cells still without a normal after the running gate pass
     C_PRECHG,       // unoccupied cells whose single dependant changed in the running clean pass
+    C_TOUCHED_SINGLE, // host mirror only (sum of word 4 of the striped lines): touched cells of the running pass in single-run bricks
     C_TABLE_MISS,   // work items of k_update_cells that found no slot in the LDS record table (they update HBM directly)
     C_COUNT = 32
 };
@@ -120,7 +125,12 @@ struct Tables {
     uint32_t* prereg_list;
     uint32_t* prechg_list;
     uint32_t* touched_list;
-    uint32_t* touched_old;   // per touched_list entry: the cell's dependant-list length before the running pass
+    // per brick: the point-log run k_buffer appended last (first entry, length) and how many appends the brick has seen (+ 0x100 for
+    // every entry that reached the log outside a run).  A brick with exactly ONE run holds all its buffered points contiguously:
+    // its replay streams that run (k_update_cells in replay mode) instead of walking the cells' chains.
+    uint32_t* run_start;
+    uint32_t* run_len;
+    uint32_t* run_cnt;
     uint64_t* cand_key;    // clean scratch (unsorted / sorted ping-pong handled by the host)
     float* frame_vp;       // 3 per frame id
     unsigned long long* ctr;

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HFPF_ABI_VERSION 3
+#define HFPF_ABI_VERSION 4
 
 /* hfpf_config.flags */
 #define HFPF_FLAG_FUSE_COLOR 1u /* EXTENSION: also average the member points' RGB per voxel (reference: never, grid.hpp:471-479) */
@@ -109,6 +109,8 @@ typedef struct hfpf_counters {
     uint64_t clean_passes;
     uint64_t device_bytes;      /* HBM allocated by this handle */
     uint64_t replay_members;    /* buffered points found inside a cylinder when replayed by a clean pass (grid.hpp:418-440) */
+    uint64_t points_direct;     /* of points_buffered: appended by k_integrate itself (no bin region or a full one), outside the bricks' runs */
+    uint64_t table_misses;      /* work items of the dependant update that found no slot in the LDS record table (updated HBM directly) */
 } hfpf_counters;
 
 void hfpf_default_config(hfpf_config* cfg);
@@ -131,7 +133,10 @@ int hfpf_get_dims(const hfpf_handle* h, int32_t dims[3], double* resolution);
  *               reference's first-row rule, i.e. n_points = row_step / point_step (node.cpp:185,190).
  *   off_*       byte offsets of the f32 fields x,y,z,rgb inside a record (fields[0..3].offset).
  *   pose_3x4    fusion_frame <- camera, row-major 3x4 f64 (the Affine3d of node.cpp:338).
- * The buffer is copied before the call returns.  Frame ids count up from 0 per handle. */
+ * The buffer is copied before the call returns.  Frame ids count up from 0 per handle.
+ * The frame's kernels are launched at once when the engine's stream is idle; while it is busy with earlier frames the frame
+ * waits (already uploading) and is launched together with the frames behind it, at most HFPF_HOST_BATCH (default 4) per launch.
+ * Any other call on the handle launches what is waiting first; an error of a deferred launch is returned by that call. */
 int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x,
                    uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double pose_3x4[12]);
 
