@@ -11,6 +11,7 @@
 
 #include <dlfcn.h>
 #include <sched.h>
+#include <sys/mman.h>
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <emmintrin.h>
@@ -1751,7 +1752,18 @@ static int extract_locked(hfpf_handle* h, const unsigned long long* stats, const
     hipLaunchKernelGGL(k_extract_rows, dim3(blocks_for(nr, 256)), dim3(256), 0, h->stream, h->g, t, stats, nr, opt, (const uint64_t*)h->keys_b.p,
                        (const uint32_t*)h->vals_b.p, (Row*)h->rows_dev.p);
     HIPCHK(h, hipGetLastError());
-    hfpf_row* host = (hfpf_row*)malloc(nr * sizeof(hfpf_row));
+    // (2 MB-aligned and advised as huge pages: a fresh 125 MB result is then ~60 page faults instead of 30,000 while it is filled)
+    hfpf_row* host = nullptr;
+    {
+        void* mem = nullptr;
+        const size_t want = nr * sizeof(hfpf_row);
+        if (want >= (4u << 20) && posix_memalign(&mem, 2u << 20, (want + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1)) == 0) {
+            (void)madvise(mem, (want + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1), MADV_HUGEPAGE);
+            host = (hfpf_row*)mem;
+        } else {
+            host = (hfpf_row*)malloc(want);
+        }
+    }
     if (!host) return fail(h, HFPF_ERR_CAPACITY, "extract: host allocation of %llu rows failed", (unsigned long long)nr);
     // The rows go to pageable memory the caller will free(): a direct device-to-pageable copy runs at ~10 GB/s through the
     // runtime's own staging.  Two pinned 16 MB buffers instead: chunk i+1 crosses the link while chunk i is copied out by the
