@@ -878,13 +878,12 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
             if (h->h_ctr[C_NORMALS] > 0 || h->normals_possible) {  // without a normal record no cell has dependants
                 if (h->update_cells) {
                     const int shape = pick_update_shape(h, (double)n_points * n_frames, nb);
-#define HFPF_LAUNCH_UPDATE(S)                                                                                                             \
-    do {                                                                                                                                  \
-        if (color) hipLaunchKernelGGL((k_update_cells<true, S.threads, S.cap, S.slots, S.desc, S.waves>), dim3(nb), dim3(S.threads), 0, h->stream, h->g, h->t, nb); \
-        else hipLaunchKernelGGL((k_update_cells<false, S.threads, S.cap, S.slots, S.desc, S.waves>), dim3(nb), dim3(S.threads), 0, h->stream, h->g, h->t, nb);      \
-    } while (0)
-                    if (shape == 1) HFPF_LAUNCH_UPDATE(kUpdWide);
-                    else HFPF_LAUNCH_UPDATE(kUpdDense);
+#define HFPF_LAUNCH_UPDATE(C, S) \
+    hipLaunchKernelGGL((k_update_cells<C, S.threads, S.cap, S.slots, S.desc, S.waves>), dim3(nb), dim3(S.threads), 0, h->stream, h->g, h->t, nb)
+                    if (color && shape == 1) HFPF_LAUNCH_UPDATE(true, kUpdWideColor);
+                    else if (color) HFPF_LAUNCH_UPDATE(true, kUpdDenseColor);
+                    else if (shape == 1) HFPF_LAUNCH_UPDATE(false, kUpdWide);
+                    else HFPF_LAUNCH_UPDATE(false, kUpdDense);
 #undef HFPF_LAUNCH_UPDATE
                 } else {
                     if (color) hipLaunchKernelGGL(k_update<true>, dim3(nb), dim3(kUpdThreads), 0, h->stream, h->g, h->t, nb);
@@ -1296,8 +1295,8 @@ int clean_locked(hfpf_handle* h, int pre_rc)
             const uint32_t nbk = (uint32_t)h->n_bricks_known;
 #define HFPF_LAUNCH_STREAM(C, S) hipLaunchKernelGGL((k_update_cells<C, S.threads, S.cap, S.slots, S.desc, S.waves, true>), dim3(nbk), dim3(S.threads), 0, s, h->g, t, nbk)
             const bool wide = h->upd_shape_forced >= 0 ? h->upd_shape_forced == 1 : h->upd_wide;  // the shape the dependant updates of this session take
-            if (t.color && wide) HFPF_LAUNCH_STREAM(true, kUpdWide);
-            else if (t.color) HFPF_LAUNCH_STREAM(true, kUpdDense);
+            if (t.color && wide) HFPF_LAUNCH_STREAM(true, kUpdWideColor);
+            else if (t.color) HFPF_LAUNCH_STREAM(true, kUpdDenseColor);
             else if (wide) HFPF_LAUNCH_STREAM(false, kUpdWide);
             else HFPF_LAUNCH_STREAM(false, kUpdDense);
 #undef HFPF_LAUNCH_STREAM

@@ -44,7 +44,10 @@ struct FrameLayout {
 #define HFPF_REPLAY_B 3  // registrants per chain walk held in registers by k_replay
 #endif
 constexpr int kLogRegions = 64;
-constexpr uint32_t kLogChains = 4;  // interleaved chains per cell (= kChains below: entry e joins chain e mod 4 of its cell)
+#ifndef HFPF_LOG_CHAINS
+#define HFPF_LOG_CHAINS 4
+#endif
+constexpr uint32_t kLogChains = HFPF_LOG_CHAINS;  // interleaved chains per cell (= kChains below: entry e joins chain e mod kLogChains of its cell)
 constexpr uint32_t kLogUnlinked = 0x80000000u;  // log entry .w = slot | this bit until the entry is chained (then: index of the next entry)
 #ifndef HFPF_REG_TILES
 #define HFPF_REG_TILES 8  // 256-voxel tiles one workgroup of k_register takes per list reservation
@@ -561,20 +564,30 @@ constexpr int kUpd2Chunk = HFPF_UPD2_CHUNK;
 static_assert(kUpd2Chunk >= 1 && kUpd2Chunk <= 15, "k_update_cells: int32 item sums hold 15 contributions");
 constexpr uint32_t kUpd2NoDesc = ~0u;
 // The kernel is a chain of latencies per brick (dependent loads, four barriers a round), so what decides its speed is how many
-// bricks a CU works on at once, i.e. its LDS footprint -- and that is dominated by the record table (44 bytes a slot) and the
-// sorted points (12 bytes each).  Two shapes are instantiated and the host picks per launch (hfpf.hip pick_update_shape):
-//   kUpdDense  512 threads, 1024 points a round, 352-slot table: 40 KB, FOUR workgroups (32 waves, 64 VGPRs) per CU.  Bricks that
-//              update ~100 records each: the 640x480 @ 1 mm bench (591 us per 150-frame launch against 624 with the wide table).
-//   kUpdWide   512 threads, 1024 points, 512 slots: 47 KB, three workgroups.  Taken for the rest of the session once the small
+// bricks a CU works on at once and how many rounds a brick takes, i.e. how its LDS is spent -- the record table (44 bytes a slot),
+// the sorted points (12 bytes each).  Two shapes are instantiated and the host picks per launch (hfpf.hip pick_update_shape):
+//   kUpdDense  512 threads, 2048 points a round, 352-slot table: 52 KB, three workgroups (24 waves, 80 VGPRs) per CU.  Bricks that
+//              update ~100 records each: the 640x480 @ 1 mm bench.  Measured on one box, per 150-frame launch: 1024-point rounds
+//              at four workgroups 587 us, 1536 at three 602 us, 2048 at three 537 us (a 320-slot table with 1024 descriptors: 552).
+//   kUpdWide   512 threads, 1536 points, 512 slots: 53 KB, three workgroups.  Taken for the rest of the session once the small
 //              table has overflowed more than rarely (the kernel counts the items that found no slot, the host sees the count at
 //              its counter read-backs): 0.5 mm voxels put 200-300 records on a brick, and an item without a slot costs five
-//              scattered memory-side atomics (2048 x 1536 @ 0.5 mm: 1.47 ms per launch wide, 2.35 ms dense).
+//              scattered memory-side atomics (2048 x 1536 @ 0.5 mm: 1.34 ms per launch; 1.48 ms with 1024-point rounds, 1.71 ms
+//              with 2048-point rounds at two workgroups, 2.35 ms with the dense table).
 // Measured and dropped: 256 threads with 512-point rounds for bricks with few points (1.9 ms on that workload: the barriers cost
 // less, the lanes per brick are missed more).  The table takes any size (the hash is range-reduced with a multiply, not masked).
 struct UpdShape {
     int threads, cap, slots, desc, waves;
 };
-constexpr UpdShape kUpdDense{512, 1024, 352, 1024, 8}, kUpdWide{512, 1024, 512, 1024, 6};
+#ifndef HFPF_UPD_DENSE_SHAPE
+#define HFPF_UPD_DENSE_SHAPE 512, 2048, 352, 1280, 6
+#endif
+#ifndef HFPF_UPD_WIDE_SHAPE
+#define HFPF_UPD_WIDE_SHAPE 512, 1536, 512, 1024, 6
+#endif
+constexpr UpdShape kUpdDense{HFPF_UPD_DENSE_SHAPE}, kUpdWide{HFPF_UPD_WIDE_SHAPE};
+// With colour the sorted points carry 4 more bytes and a table slot 24 more: 1024-point rounds keep three workgroups on a CU.
+constexpr UpdShape kUpdDenseColor{512, 1024, 352, 1024, 6}, kUpdWideColor{512, 1024, 512, 1024, 4};
 
 // Inclusive prefix sum over the 64 lanes of a wave on the DPP data path: four row shifts and two row broadcasts, six VALU
 // instructions and no LDS traffic (__shfl_up is a ds_bpermute per step: ~60 cycles of LDS-crossbar latency each, in a chain).
@@ -1334,7 +1347,7 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
     uint32_t replayed = 0;
     uint32_t next = 0;  // next dependant entry to look at
     if (use_marks && mine) {
-        const uint32_t m = t.dep_tmp[slot];  // the four lanes of a cell read it in the same instruction, then lane 0 clears it
+        const uint32_t m = t.dep_tmp[slot];  // the lanes of a cell read it in the same instruction, then lane 0 clears it
         if (m & kTouchedMark) {
             next = min(m & kDepOldMax, cnt);
             if (sub == 0) t.dep_tmp[slot] = 0;
@@ -1394,20 +1407,20 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         }
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            // sum the four sub-chains of the cell (lanes 4i..4i+3) before the flush: one record update per (cell, registrant)
+            // sum the sub-chains of the cell (kChains adjacent lanes) before the flush: one record update per (cell, registrant)
 #pragma unroll
             for (int w = 0; w < kStatUsed; w++) {
                 long long v = d[k].v[w];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
+#pragma unroll
+                for (uint32_t o = 1; o < kChains; o <<= 1) v += __shfl_xor(v, (int)o);
                 d[k].v[w] = v;
             }
             if constexpr (COLOR) {
 #pragma unroll
                 for (int w = 0; w < 3; w++) {
                     long long v = d[k].rgb[w];
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
+#pragma unroll
+                    for (uint32_t o = 1; o < kChains; o <<= 1) v += __shfl_xor(v, (int)o);
                     d[k].rgb[w] = v;
                 }
             }
