@@ -301,7 +301,7 @@ def main():
         write_times = {"pcd_ascii_s": round(tw1 - tw0, 4), "meta_csv_s": round(tw2 - tw1, 4), "pcd_binary_s": round(tw3 - tw2, 4)}
 
     # ---- host-buffer entry point (PCIe-inclusive), informational ----
-    host_mpts = host_pinned_mpts = None
+    host_mpts = host_pinned_mpts = host_link_gbps = None
     if host_frames:
         # (a) hfpf_integrate: caller's pageable buffer -> pinned bounce copy -> upload on the copy stream -> kernels (what a ROS
         #     callback with a sensor_msgs buffer gets); (b) hfpf_integrate_pinned: upload straight from page-locked memory
@@ -319,6 +319,19 @@ def main():
             grid.integrate_pinned(pinned[f * frame_bytes:(f + 1) * frame_bytes], poses[f])
         grid.sync()
         host_pinned_mpts = len(host_frames) * NPTS / (time.perf_counter() - th) / 1e6
+        # what the link itself gives this process: the same page-locked frames as ONE hipMemcpy (best of three), no kernels
+        link_bytes = len(host_frames) * frame_bytes
+        dev_scratch = grid.device_alloc(link_bytes)
+        best = None
+        for _ in range(3):
+            grid.sync()
+            th = time.perf_counter()
+            grid.device_upload(dev_scratch, pinned[:link_bytes])
+            grid.sync()
+            dt = time.perf_counter() - th
+            best = dt if best is None else min(best, dt)
+        host_link_gbps = link_bytes / best / 1e9
+        grid.device_free(dev_scratch)
         grid.host_free(pinned)
 
     total_pts = n_frames * NPTS * world
@@ -419,6 +432,8 @@ def main():
             "integrate_kernel_mpts": round(R * n_frames * NPTS / (k_ms / 1e3) / 1e6, 3) if k_ms > 0 else None,
             "host_path_mpts": round(host_mpts, 3) if host_mpts else None,  # PCIe inclusive, one frame per call, never `value`
             "host_path_pinned_mpts": round(host_pinned_mpts, 3) if host_pinned_mpts else None,
+            # one hipMemcpy of the same page-locked frames: the link's own rate on this box (the pinned path's ceiling: x / 16 B per point)
+            "host_link_GBps": round(host_link_gbps, 2) if host_link_gbps else None,
             "host_path_frames": len(host_frames),
             "counters": {k: int(v) for k, v in ctr.items()},
             "warnings": warnings,

@@ -196,6 +196,7 @@ struct hfpf_handle {
     uint64_t frames_integrated = 0;
     bool normals_possible = false;   // a clean pass has run since the last clear (the host mirror of C_NORMALS may lag behind a no-wait pass)
     bool stream_replay = true;       // HFPF_STREAM_REPLAY=0: every replay walks the chains
+    float bin_slack = 2.0f;          // planned capacity of a bin region = the brick's demand in the previous launch x this (HFPF_BIN_SLACK)
     bool clean_small_nowait = true;  // small clean passes run without a mid-pass read-back (HFPF_CLEAN_NOWAIT=0 restores it)
     uint64_t gate_done = 0; // occ_list entries already examined by a gate pass
     // A capacity / HIP / collective error in the middle of a clean pass leaves the tables half updated: the handle then refuses
@@ -250,6 +251,7 @@ struct hfpf_handle {
     bool bin_spare = true;        // HFPF_BIN_SPARE=0: no bin regions for bricks the launch discovers
     float test_bin_scale = 1.f;   // tests only (HFPF_TEST_BIN_SCALE): shrinks the planned bin regions so that they overflow into the direct forms
     DevBuf bin_pt_buf, bin_rgb_buf;
+    DevBuf ovf_pt_buf, ovf_aux_buf;  // overflow list of one integrate launch (points that found no room in a bin)
 
     // multi-GPU: RCCL is resolved at run time so a single-GPU user needs no librccl
     bool dist_on = false;
@@ -321,6 +323,14 @@ int dev_alloc(hfpf_handle* h, T** out, uint64_t count, int memset_byte = 0, bool
     if (do_memset) HIPCHK(h, hipMemsetAsync(p, memset_byte, bytes, h->stream));
     *out = (T*)p;
     return HFPF_OK;
+}
+
+// Entries the bin pool of a launch of `pts` points needs: every brick has two regions, each planned for the brick's whole demand of
+// the previous launch x slack (x 1.5 at least when the plan comes from the dry run's sample) + 64.
+uint64_t bin_pool_entries(const hfpf_handle* h, uint64_t pts, uint64_t bricks)
+{
+    const double per_point = 2.0 * std::max(1.5, (double)h->bin_slack) + 0.125;
+    return (uint64_t)(per_point * (double)pts) + 128ull * (bricks + 1);
 }
 
 int scratch(hfpf_handle* h, DevBuf& b, size_t bytes)
@@ -438,6 +448,7 @@ int check_device_errors(hfpf_handle* h)
     if (e & E_SPIN) what += " brick-claim spin bound";
     if (e & E_DEPCNT) what += " >65535 dependants on one cell";
     if (e & E_FRAME) what += " frame id >= max_frames";
+    if (e & E_OVF) what += " integrate overflow list";
     return fail(h, HFPF_ERR_CAPACITY, "device pool overflow:%s", what.c_str());
 }
 
@@ -809,7 +820,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     if (bin) {
         // pool for this launch's parked points (+25 % plan slack, +64 per brick)
         const uint64_t pts = (uint64_t)n_points * n_frames;
-        uint64_t pool = 2 * (pts + pts / 3) + 128ull * (nb_known + 1);  // two regions per brick, each sized for the whole brick
+        uint64_t pool = bin_pool_entries(h, pts, nb_known);  // two regions per brick, each sized for the whole brick
         if (spare) {  // an average brick's share of the batch, both regions, within what a 32-bit index still addresses
             spare_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pts / std::max(1u, nb_known), 64), 1u << 15);
             const uint64_t room = 0xFFFFFFFFull - std::min<uint64_t>(pool, 0xFFFFFFFFull);
@@ -825,12 +836,21 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         }
         h->t.bin_pt = (float4*)h->bin_pt_buf.p;
         h->t.bin_rgb = (uint32_t*)h->bin_rgb_buf.p;
+        // the overflow list holds a whole launch: a batch without a plan, or one that looks at a new part of the scene, parks nothing
+        if (h->ovf_pt_buf.bytes < pts * sizeof(float4) || h->ovf_aux_buf.bytes < pts * sizeof(uint2)) {
+            int rc2 = scratch(h, h->ovf_pt_buf, pts * sizeof(float4));
+            if (!rc2) rc2 = scratch(h, h->ovf_aux_buf, pts * sizeof(uint2));
+            if (rc2) return rc2;
+        }
+        h->t.ovf_pt = (float4*)h->ovf_pt_buf.p;
+        h->t.ovf_aux = (uint2*)h->ovf_aux_buf.p;
+        h->t.ovf_cap = pts;
         if (have_plan) {
             const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points)) * h->test_bin_scale;
             const uint32_t n_regions = 2u * (nb_known + 1u);  // two per brick: cells with / without a normal
             const uint32_t n_planned = 2u * (nb + 1u);        // ... and the spare ones behind them
             hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(n_planned, 256)), dim3(256), 0, h->stream, h->t, n_regions, n_planned, spare_cap, scale,
-                               h->bin_from_probe ? 1.5f : 1.25f);
+                               h->bin_from_probe ? std::max(1.5f, h->bin_slack) : h->bin_slack);
             h->bin_from_probe = false;
             size_t bytes = 0;
             HIPCHK(h, rocprim::exclusive_scan(nullptr, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_planned, rocprim::plus<uint32_t>(), h->stream));
@@ -841,6 +861,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
             const uint32_t all_regions = 2u * (uint32_t)(h->t.max_bricks + 2);
             hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(all_regions, 256)), dim3(256), 0, h->stream, h->t, n_planned, all_regions, h->bin_pool);
         } else {  // no plan yet: no region exists, every lane takes the direct forms, the demand is recorded
+            HIPCHK(h, hipMemsetAsync(&h->t.ctr[C_OVF], 0, sizeof(unsigned long long), h->stream));  // (k_bin_clamp does this where there is a plan)
             HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
             HIPCHK(h, hipMemsetAsync(h->t.bin_capb, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
         }
@@ -873,6 +894,11 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, true);
         else if (!color) HFPF_LAUNCH_INTEGRATE(false, false, true);
         else HFPF_LAUNCH_INTEGRATE(false, true, true);
+        {  // the points that found no room in a bin (usually a few thousand, everything for a batch without a plan): direct forms
+            const unsigned ogrid = (unsigned)std::min<uint64_t>(blocks_for((uint64_t)n_points * n_frames, 256), 8ull * 256);
+            if (color) hipLaunchKernelGGL(k_integrate_overflow<true>, dim3(ogrid), dim3(256), 0, h->stream, h->g, h->t, log_rot);
+            else hipLaunchKernelGGL(k_integrate_overflow<false>, dim3(ogrid), dim3(256), 0, h->stream, h->g, h->t, log_rot);
+        }
         HIPCHK(h, detail_mark());
         if (have_plan) {
             if (h->h_ctr[C_NORMALS] > 0 || h->normals_possible) {  // without a normal record no cell has dependants
@@ -1391,6 +1417,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         if (const char* us = getenv("HFPF_UPD_SHAPE")) h->upd_shape_forced = std::max(0, std::min(atoi(us), 1));
         if (const char* sp = getenv("HFPF_BIN_SPARE")) h->bin_spare = sp[0] != '0';
         if (const char* sr = getenv("HFPF_STREAM_REPLAY")) h->stream_replay = sr[0] != '0';
+        if (const char* bs = getenv("HFPF_BIN_SLACK")) h->bin_slack = std::max(1.0f, std::min(4.0f, (float)atof(bs)));
         if (const char* nw = getenv("HFPF_CLEAN_NOWAIT")) h->clean_small_nowait = nw[0] != '0';
         if (const char* bs = getenv("HFPF_TEST_BIN_SCALE")) h->test_bin_scale = std::max(0.f, std::min(1.f, (float)atof(bs)));
         const char* mb = getenv("HFPF_MAILBOX");
@@ -1404,7 +1431,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         int per_cu = 0, cus = 0;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_integrate<true, false, false>, 256, 0) != hipSuccess) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->binned ? k_integrate<true, false, true> : k_integrate<true, false, false>, 256, 0) != hipSuccess) per_cu = 4;
         h->integrate_grid = std::max(1, per_cu) * std::max(1, cus);
     }
     if ((rc = alloc_tables(h))) return bail(rc);
@@ -1417,10 +1444,11 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
             return bail(rc);
         if (h->cfg.max_call_points && h->binned) {
             const uint64_t pts = h->cfg.max_call_points;
-            const uint64_t pool = std::min<uint64_t>(2 * (pts + pts / 3) + 128ull * (h->cfg.max_bricks + 1), 0xFFFFFFFFull);
+            const uint64_t pool = std::min<uint64_t>(bin_pool_entries(h, pts, h->cfg.max_bricks), 0xFFFFFFFFull);
             if ((rc = scratch(h, h->bin_pt_buf, pool * sizeof(float4)))) return bail(rc);
             if (h->t.color && (rc = scratch(h, h->bin_rgb_buf, pool * 4))) return bail(rc);
             h->bin_pool = pool;
+            if ((rc = scratch(h, h->ovf_pt_buf, pts * sizeof(float4))) || (rc = scratch(h, h->ovf_aux_buf, pts * sizeof(uint2)))) return bail(rc);
         }
     }
     for (int k = 0; k < 2; k++) {  // (a failure here only costs speed: extract then copies straight into pageable memory)
@@ -1445,7 +1473,7 @@ int hfpf_destroy(hfpf_handle* h)
     for (DevBuf* b : {&h->sort_tmp, &h->keys_a, &h->keys_b, &h->vals_a, &h->vals_b, &h->rows_dev, &h->probe_a, &h->probe_b, &h->probe_c, &h->probe_d,
                       &h->probe_e, &h->probe_f})
         if (b->p) (void)hipFree(b->p);
-    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->bin_pt_buf, &h->bin_rgb_buf, &h->pend_a, &h->pend_b})
+    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->bin_pt_buf, &h->bin_rgb_buf, &h->ovf_pt_buf, &h->ovf_aux_buf, &h->pend_a, &h->pend_b})
         if (b->p) (void)hipFree(b->p);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t_)h->comm);
     if (h->h_counts) (void)hipHostFree(h->h_counts);

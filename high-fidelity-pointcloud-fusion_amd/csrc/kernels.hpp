@@ -123,13 +123,116 @@ __device__ __forceinline__ void flush_occ_stage(const Tables& t, const uint32_t*
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Seven waves per SIMD (<= 72 VGPRs, no scratch): the tile loop is a chain of dependent table round trips, so resident waves are
-// what hides them; eight would spill.
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP data path: four row shifts and two row broadcasts, six VALU
+// instructions and no LDS traffic (__shfl_up is a ds_bpermute per step: ~60 cycles of LDS-crossbar latency each, in a chain).
+#ifndef HFPF_DPP_SCAN
+#define HFPF_DPP_SCAN 1
+#endif
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+#if HFPF_DPP_SCAN
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1, zero shifted in
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+#else
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(v, o);
+        if (lane >= (uint32_t)o) v += a;
+    }
+    return v;
+#endif
+}
+
+// The direct forms of buffering (grid.hpp:205-243) and of the dependant update (grid.hpp:244-277) for one point per lane: the whole
+// path of the un-binned engine (BIN = false, inline in k_integrate), and in the binned one what k_integrate_overflow does with the
+// few points that found no room in their brick's bin.  Convergent for the wave (every lane calls; `todo` says which have a point).
+constexpr uint32_t kOvfHasNormal = 0x80000000u, kOvfHasDeps = 0x40000000u;  // flags beside the frame id (< 2^23, host-checked) in Tables::ovf_aux
+template <bool COLOR, bool BIN>
+__device__ __forceinline__ void direct_buffer(const Tables& t, unsigned long long* log_ctr, const uint64_t log_base, const F3 p, const uint32_t slot, const uint32_t b,
+                                              const uint32_t fid, const uint32_t rgb, const bool todo, const bool has_n, uint32_t& c_buf)
+{
+    // direct buffering; the viewpoint latch (smallest frame id that touched the cell, grid.hpp:229,238) is only ever
+    // read before the normal exists
+    const bool buf = todo && !has_n;
+    if (buf && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
+    const unsigned long long li = wave_reserve(log_ctr, buf);
+    if (buf) {
+        if (li < t.log_region_cap) {
+            const uint64_t e = log_base + li + 1;
+            // Binned form: this is the rare lane whose bin region was full, so it chains its entry right here (one returning
+            // atomic) and no pass over the log is needed afterwards.  Direct form (every point comes this way): .w carries the
+            // marked slot until k_link_log chains the entries of the epoch in one go.
+            uint32_t link = slot | kLogUnlinked;
+            if (BIN) {
+                link = atomicExch(&t.buf_head[(uint64_t)slot * kLogChains + ((uint32_t)e & (kLogChains - 1))], (uint32_t)e);
+                if (!(t.run_cnt[b] & 0x100u)) atomicOr(&t.run_cnt[b], 0x100u);  // an entry outside the brick's runs: its replay walks the chains
+            }
+            t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(link));
+            if (COLOR) t.log_rgb[e] = rgb;
+        } else {
+            atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
+        }
+    }
+    c_buf += buf;
+}
+
+template <bool COLOR, bool BIN>
+__device__ __forceinline__ void direct_forms(const GridParams& g, const Tables& t, unsigned long long* q, unsigned long long* log_ctr, const uint64_t log_base,
+                                             const F3 p, const uint32_t slot, const uint32_t b, const uint32_t fid, const uint32_t rgb, const bool todo,
+                                             const bool has_n, const bool has_d, uint32_t& c_buf, uint32_t& c_tested, uint32_t& c_member)
+{
+    direct_buffer<COLOR, BIN>(t, log_ctr, log_base, p, slot, b, fid, rgb, todo, has_n, c_buf);
+
+    // direct dependant updates
+    const bool direct = todo && has_d;
+    uint32_t cnt = 0;
+    uint64_t off = 0;
+    if (direct) {
+        const uint64_t info = t.info[slot];
+        cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+        off = info >> kDepOffShift;
+    }
+    uint32_t max_cnt = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, o));
+    for (uint32_t j = 0; j < max_cnt; j++) {
+        bool member = false;
+        StatDeltaT<COLOR> d;
+        stat_delta_zero(d);
+        uint32_t sid = 0;
+        if (j < cnt) {
+            const DepEntry e = t.dep[off + j];
+            float sp, distf;
+            c_tested++;
+            if (line_member(g, p, F3{e.ax, e.ay, e.az}, F3{e.abx, e.aby, e.abz}, e.dd, sp, distf)) {
+                member = true;
+                c_member++;
+                sid = e.sid;
+                stat_delta_add(d, pair_delta(g, sp, distf), rgb);
+            }
+        }
+        wave_flush_members(t, q, member, d, sid);
+    }
+}
+
+// Waves per SIMD: the tile loop is a chain of dependent table round trips, so resident waves are what hides them.  The binned form
+// (direct forms moved out to k_integrate_overflow) needs 59 VGPRs and runs eight waves per SIMD; asking the compiler for eight shrinks its
+// SGPR budget (94 -> 78, 51 spills instead of 37), so the bound stays at seven.  The un-binned form fits seven (<= 72 VGPRs, no scratch).
 #ifndef HFPF_INT_WAVES
 #define HFPF_INT_WAVES 7
 #endif
+#ifndef HFPF_INT_WAVES_BIN
+#define HFPF_INT_WAVES_BIN 7
+#endif
 template <bool PACKED16, bool COLOR, bool BIN>
-__global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
+__global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
                                                    const uint32_t* __restrict__ frame_ids, const uint32_t row_w, const uint32_t log_rot,
@@ -324,59 +427,21 @@ __global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridPar
         }
         if (probe || __ballot(todo) == 0) continue;  // wave-uniform; the common case of the binned form
 
-        // direct buffering; the viewpoint latch (smallest frame id that touched the cell, grid.hpp:229,238) is only ever
-        // read before the normal exists
-        const bool buf = todo && !has_n;
-        if (buf && fid < t.first_frame[slot]) atomicMin(&t.first_frame[slot], fid);
-        const unsigned long long li = wave_reserve(log_ctr, buf);
-        if (buf) {
-            if (li < t.log_region_cap) {
-                const uint64_t e = log_base + li + 1;
-                // Binned form: this is the rare lane whose bin region was full, so it chains its entry right here (one returning
-                // atomic) and no pass over the log is needed afterwards.  Direct form (every point comes this way): .w carries the
-                // marked slot until k_link_log chains the entries of the epoch in one go.
-                uint32_t link = slot | kLogUnlinked;
-                if (BIN) {
-                    link = atomicExch(&t.buf_head[(uint64_t)slot * kLogChains + ((uint32_t)e & (kLogChains - 1))], (uint32_t)e);
-                    if (!(t.run_cnt[b] & 0x100u)) atomicOr(&t.run_cnt[b], 0x100u);  // an entry outside the brick's runs: its replay walks the chains
-                }
-                t.log_pt[e] = make_float4(p.x, p.y, p.z, __uint_as_float(link));
-                if (COLOR) t.log_rgb[e] = rgb;
-            } else {
-                atomicOr(&t.ctr[C_ERR], (unsigned long long)E_LOG);
-            }
-        }
-        c_buf += buf;
-
-        // direct dependant updates
-        const bool direct = todo && has_d;
-        uint32_t cnt = 0;
-        uint64_t off = 0;
-        if (direct) {
-            const uint64_t info = t.info[slot];
-            cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-            off = info >> kDepOffShift;
-        }
-        uint32_t max_cnt = cnt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) max_cnt = max(max_cnt, (uint32_t)__shfl_xor((int)max_cnt, o));
-        for (uint32_t j = 0; j < max_cnt; j++) {
-            bool member = false;
-            StatDeltaT<COLOR> d;
-            stat_delta_zero(d);
-            uint32_t sid = 0;
-            if (j < cnt) {
-                const DepEntry e = t.dep[off + j];
-                float sp, distf;
-                c_tested++;
-                if (line_member(g, p, F3{e.ax, e.ay, e.az}, F3{e.abx, e.aby, e.abz}, e.dd, sp, distf)) {
-                    member = true;
-                    c_member++;
-                    sid = e.sid;
-                    stat_delta_add(d, pair_delta(g, sp, distf), rgb);
+        if constexpr (BIN) {
+            // The rare lane whose bin region was full or unplanned: handed, with what the direct forms need, to k_integrate_overflow,
+            // which runs behind this kernel.  Keeping the direct forms out of the tile loop halves the scalar state this kernel
+            // spills into VGPR lanes (60 -> 30 SGPRs) and frees 19 VGPRs (eight waves per SIMD).
+            const unsigned long long oi = wave_reserve(&t.ctr[C_OVF], todo);
+            if (todo) {
+                if (oi < t.ovf_cap) {
+                    t.ovf_pt[oi] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
+                    t.ovf_aux[oi] = make_uint2(fid | (has_n ? kOvfHasNormal : 0u) | (has_d ? kOvfHasDeps : 0u), rgb);
+                } else {
+                    atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OVF);  // (the list holds a whole launch: cannot happen)
                 }
             }
-            wave_flush_members(t, q, member, d, sid);
+        } else {
+            direct_forms<COLOR, false>(g, t, q, log_ctr, log_base, p, slot, b, fid, rgb, todo, has_n, has_d, c_buf, c_tested, c_member);
         }
     }
     if (occ_n) flush_occ_stage(t, s_occ, occ_n);  // wave-uniform
@@ -399,6 +464,105 @@ __global__ __launch_bounds__(256, HFPF_INT_WAVES) void k_integrate(const GridPar
     if (!probe && threadIdx.x < 6 && blk_ctr[threadIdx.x]) atomicAdd(&t.ctr[C_PRESENTED + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
 }
 
+
+// K1b (binned form): the points k_integrate could not park (bin region full, brick unplanned or found within the launch after the
+// spare regions ran out: 0.3 % of the bench's points) take the direct forms here, right behind it on the stream.  The list is sized
+// for a whole launch, so a session without a bin plan (its first small batch) comes through here entirely.  A workgroup takes 256
+// points at a time: one lane per point for the buffering, then one lane per (point, dependant) PAIR -- the pairs of the 256 points
+// are numbered through a prefix sum of the list lengths, so a point on a cell with twenty dependants does not hold its wave for
+// twenty dependent reads.  The list is reset by the next launch's bin plan (k_bin_clamp; the host where there is no plan).
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_integrate_overflow(const GridParams g, const Tables t, const uint32_t log_rot)
+{
+    __shared__ unsigned long long queue[4][kQueueRows * kQueueStride];
+    __shared__ unsigned int blk_ctr[3];
+    __shared__ float s_x[256], s_y[256], s_z[256];
+    __shared__ uint32_t s_rgb[COLOR ? 256 : 1];
+    __shared__ uint32_t s_off[256];    // first dependant entry of the point's cell (dep[] stays below 2^32 entries, host-checked)
+    __shared__ uint32_t s_pref[257];   // pairs in front of the point
+    __shared__ uint32_t s_wsum[4];
+    const uint64_t n = min((uint64_t)t.ctr[C_OVF], t.ovf_cap);  // the same in every thread of the grid (nothing appends while this kernel runs)
+    if (n == 0) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned long long* q = queue[wave];
+    if (tid < 3) blk_ctr[tid] = 0;
+    __syncthreads();
+    const uint32_t region = (blockIdx.x + log_rot) & (kLogRegions - 1);
+    unsigned long long* log_ctr = &t.log_ctr[region * 16];
+    const uint64_t log_base = (uint64_t)region * t.log_region_cap;
+    uint32_t c_buf = 0, c_tested = 0, c_member = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < n; base += (uint64_t)gridDim.x * 256u) {  // block-uniform trip count
+        const uint64_t i = base + tid;
+        const bool todo = i < n;
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 aux = make_uint2(0u, 0u);
+        if (todo) {
+            rec = t.ovf_pt[i];
+            aux = t.ovf_aux[i];
+        }
+        const uint32_t slot = __float_as_uint(rec.w);
+        uint32_t cnt = 0, off = 0;
+        if (todo && (aux.x & kOvfHasDeps)) {  // issued before the buffering's atomics
+            const uint64_t info = t.info[slot];
+            cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+            off = (uint32_t)(info >> kDepOffShift);
+        }
+        direct_buffer<COLOR, true>(t, log_ctr, log_base, F3{rec.x, rec.y, rec.z}, slot, slot >> 9, aux.x & ~(kOvfHasNormal | kOvfHasDeps), aux.y, todo,
+                                   (aux.x & kOvfHasNormal) != 0, c_buf);
+        const uint32_t inc = wave_inclusive_scan(cnt);
+        if (lane == 63) s_wsum[wave] = inc;
+        s_x[tid] = rec.x, s_y[tid] = rec.y, s_z[tid] = rec.z;
+        if (COLOR) s_rgb[tid] = aux.y;
+        s_off[tid] = off;
+        __syncthreads();
+        uint32_t pre = inc - cnt;
+        for (uint32_t w2 = 0; w2 < wave; w2++) pre += s_wsum[w2];
+        s_pref[tid] = pre;
+        if (tid == 255) s_pref[256] = pre + cnt;
+        __syncthreads();
+        const uint32_t total = s_pref[256];
+        for (uint32_t k0 = 0; k0 < total; k0 += 256u) {  // block-uniform trip count
+            const uint32_t k = k0 + tid;
+            bool member = false;
+            StatDeltaT<COLOR> d;
+            stat_delta_zero(d);
+            uint32_t sid = 0;
+            if (k < total) {
+                uint32_t lo = 0, hi = 256;  // s_pref[lo] <= k < s_pref[hi]
+#pragma unroll
+                for (int st = 0; st < 8; st++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= k) lo = mid;
+                    else hi = mid;
+                }
+                const DepEntry e = t.dep[(uint64_t)s_off[lo] + (k - s_pref[lo])];
+                float sp, distf;
+                c_tested++;
+                if (line_member(g, F3{s_x[lo], s_y[lo], s_z[lo]}, F3{e.ax, e.ay, e.az}, F3{e.abx, e.aby, e.abz}, e.dd, sp, distf)) {
+                    member = true;
+                    c_member++;
+                    sid = e.sid;
+                    stat_delta_add(d, pair_delta(g, sp, distf), COLOR ? s_rgb[lo] : 0u);
+                }
+            }
+            wave_flush_members(t, q, member, d, sid);
+        }
+        __syncthreads();  // the staged points are rewritten by the next round
+    }
+    uint32_t cv[3] = {c_buf, c_tested, c_member};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t v = cv[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (lane == 0 && v) atomicAdd(&blk_ctr[k], v);
+    }
+    __syncthreads();
+    if (tid < 3 && blk_ctr[tid]) atomicAdd(&t.ctr[C_BUFFERED + tid], (unsigned long long)blk_ctr[tid]);
+#ifdef HFPF_OVF_COUNT_DEBUG
+    if (tid == 0 && blockIdx.x == 0) atomicAdd(&t.ctr[C_BUFFERED], (unsigned long long)n);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // K2 (binned form): one workgroup per brick.  The brick's parked points are read back coalesced; a point finds its cell's
@@ -588,33 +752,6 @@ struct UpdShape {
 constexpr UpdShape kUpdDense{HFPF_UPD_DENSE_SHAPE}, kUpdWide{HFPF_UPD_WIDE_SHAPE};
 // With colour the sorted points carry 4 more bytes and a table slot 24 more: 1024-point rounds keep three workgroups on a CU.
 constexpr UpdShape kUpdDenseColor{512, 1024, 352, 1024, 6}, kUpdWideColor{512, 1024, 512, 1024, 4};
-
-// Inclusive prefix sum over the 64 lanes of a wave on the DPP data path: four row shifts and two row broadcasts, six VALU
-// instructions and no LDS traffic (__shfl_up is a ds_bpermute per step: ~60 cycles of LDS-crossbar latency each, in a chain).
-#ifndef HFPF_DPP_SCAN
-#define HFPF_DPP_SCAN 1
-#endif
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
-{
-#if HFPF_DPP_SCAN
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1, zero shifted in
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
-    return (uint32_t)x;
-#else
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t a = __shfl_up(v, o);
-        if (lane >= (uint32_t)o) v += a;
-    }
-    return v;
-#endif
-}
 
 // REPLAY = true is the buffer replay of a clean pass (grid.hpp:418-440) for bricks whose buffered points form ONE contiguous run of
 // the point log (Tables::run_*): the same kernel with the run as its input instead of the bin -- the cell of a logged point is
@@ -965,14 +1102,15 @@ __global__ __launch_bounds__(256) void k_buffer(const GridParams g, const Tables
     }
 }
 
-// Plan the bin regions of the next launch from the demand of the previous one: cap = demand * scale * slack + 64 (slack 1.25; 1.5
-// when the demand is the dry run's sample of 8 frames, whose per-brick counts scatter more), where the
+// Plan the bin regions of the next launch from the demand of the previous one: cap = demand * scale * slack + 64 (slack 2: a brick's
+// share of a launch moves with the poses of its frames -- 15-frame launches of the 0.5 mm workload left 1 % of their points without
+// room at 1.25, 0.5 % at 2), where the
 // demand is the BRICK's (both regions): a clean pass between two launches moves cells from "no normal" to "normal", so either
 // region must be able to take all of the brick's points.  n_regions = 2 * (bricks + 1); regions 0 and 1 belong to the null
 // brick and stay empty.
 // Regions [n_regions, n_planned) belong to brick ids the host has not seen yet: ids are handed out in order, so the next bricks a
-// launch discovers find a region of `spare_cap` entries waiting (without one all their points take the direct forms inside
-// k_integrate -- in the first epoch of a session that was one point in N).
+// launch discovers find a region of `spare_cap` entries waiting (without one all their points go through the overflow list and
+// take the direct forms).
 __global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_regions, const uint32_t n_planned, const uint32_t spare_cap, const float scale,
                                                   const float slack)
 {
@@ -992,7 +1130,8 @@ __global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t
 // regions restart -- also those of bricks the host has not heard of yet (claimed since its last counter read-back: they have no
 // region until then and keep recording their demand): left alone, their counters would add up over every launch until the next
 // clean pass and the plan made from them would be inflated by that factor.  With every counter holding ONE launch's demand the
-// planned capacities add up to at most 2.5 x points + 128 x bricks < the pool size, so the 32-bit scan cannot wrap.
+// planned capacities add up to at most 2 x slack x points + 128 x bricks < the pool size (hfpf.hip bin_pool_entries), so the 32-bit
+// scan cannot wrap.
 __global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_t n_regions, const uint32_t all_regions, const uint64_t pool)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1000,6 +1139,7 @@ __global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_
     // (regions behind the planned ones are off: an earlier launch may have planned more spare regions than this one)
     if (r >= n_regions || (uint64_t)t.bin_off[r] + t.bin_capb[r] > pool) t.bin_capb[r] = 0;
     t.bin_fill[r] = 0;
+    if (r == 0) t.ctr[C_OVF] = 0;  // the overflow list of the previous launch has been worked off (k_integrate_overflow)
 }
 
 // ------------------------------------------------------------------------------------------------

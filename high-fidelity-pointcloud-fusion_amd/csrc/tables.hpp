@@ -73,6 +73,7 @@ enum Ctr : int {
     C_PRECHG,       // unoccupied cells whose single dependant changed in the running clean pass
     C_TOUCHED_SINGLE, // host mirror only (sum of word 4 of the striped lines): touched cells of the running pass in single-run bricks
     C_TABLE_MISS,   // work items of k_update_cells that found no slot in the LDS record table (they update HBM directly)
+    C_OVF,          // entries in the overflow list of the running integrate launch (k_integrate -> k_integrate_overflow)
     C_COUNT = 32
 };
 
@@ -86,6 +87,7 @@ enum ErrBits : uint64_t {
     E_SPIN = 64,
     E_DEPCNT = 128,
     E_FRAME = 256,
+    E_OVF = 512,
 };
 
 struct __attribute__((aligned(32))) DepEntry {  // one dependant of a cell, denormalised for the per-point loop
@@ -137,6 +139,9 @@ struct Tables {
     // brick bins of the two-pass dependant update (kernels.hpp, k_integrate<BIN> + k_update)
     float4* bin_pt;       // (x, y, z, bits of the cell's index inside the brick) of points parked for k_update, grouped per brick
     uint32_t* bin_rgb;    // their colour (HFPF_FLAG_FUSE_COLOR only)
+    float4* ovf_pt;       // overflow list of the running integrate launch: (x, y, z, bits of the slot) of the points that found no room in a bin
+    uint2* ovf_aux;       // ... and (frame id | kOvfHasNormal | kOvfHasDeps, colour)
+    uint64_t ovf_cap;     // entries both hold (= the points of the launch)
     // Two regions per brick, index 2*brick + kind: kind 0 = points whose cell has a normal (dependant updates only),
     // kind 1 = points whose cell has none yet (to be buffered by k_buffer, and updated like the others by k_update)
     uint32_t* bin_fill;   // per region: entries requested in the running launch (may exceed the region)

@@ -10,7 +10,8 @@ Each pass ran `bench.py --repeats 1 --warmup 0 --cpu-sample 0 --host-path-frames
 hfpf_integrate_device call per clean epoch.  k_integrate dispatches: #0 = the dry run of the session's first 8 frames (bin
 demand), #1 = the first epoch (everything is buffered, no dependant exists yet), #2..#6 = steady state, 150 frames each (#7 is
 the 100-frame tail and is left out of the per-launch means); k_update dispatches #0..#4 belong to the steady launches;
-k_buffer dispatch #0 to the first epoch, #1..#5 to the steady launches.
+k_buffer dispatch #0 to the first epoch, #1..#5 to the steady launches; k_integrate_overflow dispatches (#0 first epoch, #1..#5 steady)
+are added to k_integrate's figures.
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of a wide
 (16 B/lane) coalesced stream, so 8 B per streamed 16-byte record are added (the frame read in k_integrate, the bin read-back in
 k_update); narrower scattered reads are uncalibrated.
@@ -43,7 +44,8 @@ def load(prefix):
     for f in sorted(glob.glob(prefix + "_*/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            which = "k_integrate" if "k_integrate" in k else ("k_update" if "k_update" in k else ("k_buffer" if "k_buffer" in k else None))
+            which = ("k_overflow" if "k_integrate_overflow" in k else "k_integrate" if "k_integrate" in k else
+                     "k_update" if "k_update" in k else "k_buffer" if "k_buffer" in k else None)
             if which:
                 per[which][r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
     return per
@@ -85,7 +87,9 @@ def main():
            "source": "rocprofv3 --pmc, separate passes (tools/pmc_passes.sh), bench.py --repeats 1 --warmup 0"}
     for phase, sel_a, sel_b, sel_c in (("first_epoch_buffer_only", lambda v: v[1:2], None, lambda v: v[:1]),
                                        ("steady_state_after_first_clean", lambda v: v[2:7], lambda v: v[:5], lambda v: v[1:6])):
-        ga = lambda c: mean(sel_a(series(per, "k_integrate", c)))
+        # k_integrate_overflow (one dispatch behind every k_integrate but the dry run) belongs to the integrate stage
+        sel_o = (lambda v: v[0:1]) if sel_b is None else (lambda v: v[1:6])
+        ga = lambda c: mean(sel_a(series(per, "k_integrate", c))) + mean(sel_o(series(per, "k_overflow", c)))
         gb = (lambda c: mean(sel_b(series(per, "k_update", c)))) if sel_b else (lambda c: 0.0)
         gc = lambda c: mean(sel_c(series(per, "k_buffer", c)))
         fa, wa, aa = ga("FETCH_SIZE") * 1024, ga("WRITE_SIZE") * 1024, ga("TCC_EA0_ATOMIC_sum")

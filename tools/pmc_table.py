@@ -17,7 +17,7 @@ def main():
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             for w in want:
-                if w in r["Kernel_Name"]:
+                if w in r["Kernel_Name"] and not (w == "k_integrate" and "k_integrate_overflow" in r["Kernel_Name"]):
                     per[(w, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (w, c), v in per.items():
             lo, hi = {"k_integrate": (2, -1), "k_buffer": (1, -1), "k_update": (0, -1)}.get(w, (0, None))
