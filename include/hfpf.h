@@ -109,7 +109,7 @@ typedef struct hfpf_counters {
     uint64_t clean_passes;
     uint64_t device_bytes;      /* HBM allocated by this handle */
     uint64_t replay_members;    /* buffered points found inside a cylinder when replayed by a clean pass (grid.hpp:418-440) */
-    uint64_t points_direct;     /* of points_buffered: appended by k_integrate itself (no bin region or a full one), outside the bricks' runs */
+    uint64_t points_direct;     /* of points_buffered: appended one by one through the overflow list (no bin region or a full one), outside the bricks' runs */
     uint64_t table_misses;      /* work items of the dependant update that found no slot in the LDS record table (updated HBM directly) */
 } hfpf_counters;
 

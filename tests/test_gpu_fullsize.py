@@ -136,8 +136,9 @@ def test_bench_cadence_stream_vs_oracle_and_overflowing_bins(oracle_mod, hfpf_mo
     call, clean every 60 frames, 16x16-pixel tiles -- 10^3..10^4 parked points per brick, several sort rounds per brick in
     k_update_cells, the dry run of the first call, dependant-table relocation in the second and third clean pass.  The oracle
     runs the same stream serially on the host (~30 s).  Second engine run: bin regions planned at a third of their demand
-    (HFPF_TEST_BIN_SCALE), so that most points of every brick overflow into the direct forms of k_integrate (direct log append +
-    chained entry, wave-cooperative atomic flush per member pair) beside the binned ones -- same rows, byte for byte."""
+    (HFPF_TEST_BIN_SCALE x the plan's slack of 2), so that most points of every brick go through the overflow list and take the
+    direct forms in k_integrate_overflow (direct log append + chained entry, one lane per (point, dependant) pair, wave-cooperative
+    atomic flush per member pair) beside the binned ones -- same rows, byte for byte."""
     sc = scenes.Scene(120, 640, 480, 0.001, clean_every=60)
     caps = dict(max_bricks=100000, max_log_points=48 << 20, max_normals=6 << 20, max_frames=256, frame_width=640)
     rows, ctr, dims = _stream(hfpf_mod, sc, 60, caps)
@@ -149,7 +150,7 @@ def test_bench_cadence_stream_vs_oracle_and_overflowing_bins(oracle_mod, hfpf_mo
     assert (oc["presented"], oc["zclip_pass"], oc["inserted"], oc["buffered"]) == (
         ctr["points_presented"], ctr["points_zclip_pass"], ctr["points_in_bbox"], ctr["points_buffered"])
     scenes.compare_rows(ref, rows)
-    monkeypatch.setenv("HFPF_TEST_BIN_SCALE", "0.33")
+    monkeypatch.setenv("HFPF_TEST_BIN_SCALE", "0.16")
     rows2, ctr2, _ = _stream(hfpf_mod, sc, 60, caps)
     scenes.compare_rows(ref, rows2)
     assert rows.tobytes() == rows2.tobytes(), "overflowing bin regions (direct forms) changed the result"
