@@ -650,9 +650,9 @@ int alloc_tables(hfpf_handle* h)
 
 // Cell keys: only the low GridParams::key_bits bits are significant (an all-ones sentinel still sorts behind every valid key:
 // a valid cell has x < dim <= 2^bits_x - 1, so its key is never all ones).
-int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n)
+int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n, unsigned bits = 0)
 {
-    const unsigned kb = h->g.key_bits;
+    const unsigned kb = bits ? bits : h->g.key_bits;
     size_t bytes = 0;
     HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
@@ -1232,7 +1232,9 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     h->pend_valid = true;             // C_PEND now counts pend_a; the host reads it at the start of the next pass
 
     // canonical order: ascending (x,y,z) key; record id = n_normals + rank + 1
-    if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_in))) return rc;
+    // (with HFPF_MORTON_IDS the candidate keys are Z-order codes: three interleaved axes of the widest axis' bits)
+    const unsigned cand_bits = HFPF_MORTON_IDS ? 3u * std::max(h->g.key_sy, std::max(h->g.key_sx - h->g.key_sy, h->g.key_bits - h->g.key_sx)) : h->g.key_bits;
+    if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_in, cand_bits))) return rc;
     hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_in, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, kCountOnDevice, n_normals);
     const uint64_t reg_tile = 256ull * kRegTiles;  // step-major, whole workgroups (kRegTiles tiles each) per step
     const uint64_t reg_blocks = ((n_in + reg_tile - 1) / reg_tile) * (2ull * (uint64_t)h->g.K + 1ull);

@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_gate(const GridParams g, const Tables t
                 const int total = __popcll(lo) + __popcll(hi);
                 if (total > g.gate) n_pass[tt] = 1;
                 else n_pend[tt] = 1;  // still without a normal: look at it again next pass (its neighbourhood may fill up)
-                key_[tt] = make_key(g, x, y, z);
+                key_[tt] = HFPF_MORTON_IDS ? morton_key(x, y, z) : make_key(g, x, y, z);  // the order the pass numbers its records in
             }
         }
     }
@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(256) void k_clean_begin(const Tables t, const uint6
     if (i < (uint64_t)kLogRegions) t.log_ctr[i * 16 + 4] = 0;  // touched cells in single-run bricks (k_depinc_offsets)
 }
 
-// K4: one thread per candidate, in ascending key order; record id = base + rank + 1.
+// K4: one thread per candidate, in ascending order of the sorted keys (Z-order codes with HFPF_MORTON_IDS); record id = base + rank + 1.
 __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables t, const uint64_t* __restrict__ sorted_keys,
                                                 const uint64_t n_cand_arg, const uint64_t base)
 {
@@ -1307,9 +1307,14 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
         t.ctr[C_NORMALS] = base + n_cand;
     }
     if (r >= n_cand) return;
-    const uint64_t key = sorted_keys[r];
     int32_t x, y, z;
-    key_coords(g, key, x, y, z);
+    uint64_t key = sorted_keys[r];
+    if (HFPF_MORTON_IDS) {
+        morton_coords(key, x, y, z);
+        key = make_key(g, x, y, z);  // what the record keeps: the canonical (x, y, z) key (extract order, registration contests)
+    } else {
+        key_coords(g, key, x, y, z);
+    }
     const uint32_t slot = slot_lookup(g, t, x, y, z);
     uint64_t lo, hi;
     neighbourhood(g, t, x, y, z, lo, hi);
@@ -1367,8 +1372,8 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
 }
 
 // K5: one thread per (new normal, line step).  Occupancy is frozen during a clean pass, so the steps are
-// independent; "last registrant wins" on unoccupied cells (grid.hpp:443-449) is an atomicMax over
-// record ids, which ascend with the canonical key order inside a pass and across passes.
+// independent; "last registrant wins" on unoccupied cells (grid.hpp:443-449) is an atomicMax over record ids -- they ascend from
+// pass to pass -- with the contests inside a pass settled by the canonical (x, y, z) key (see below: ids follow the Z-order there).
 __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand_arg, const uint64_t base)
 {
     const uint64_t n_cand = n_cand_arg == kCountOnDevice ? cand_count(t, base) : n_cand_arg;  // the same in every thread
@@ -1413,6 +1418,24 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
             const uint32_t old = atomicMax(&t.pre_dep[slot], (uint32_t)nid);
             if (old == 0u) f_new |= 1u << tt;    // first registration ever on this cell
             if (old <= base) f_chg |= 1u << tt;  // first change in THIS pass (ids of this pass are > base): exactly one lane sees it
+            if (HFPF_MORTON_IDS && old > base && old != (uint32_t)nid) {
+                // Another voxel of this pass registered here as well.  Ids follow the Z-order inside a pass, the contest is about the
+                // canonical order: the registrant with the LARGEST (x, y, z) KEY stays (the reference walks its candidates in that
+                // order and the last one overwrites, grid.hpp:443-449).  The atomicMax above has put the larger ID into the cell and
+                // told this lane whom it met; the lane now sees to it that the cell holds a key at least as large as the better of the
+                // two.  Whoever displaces a holder learns of it the same way and takes over that duty, so once every registrant is
+                // through, the cell holds the largest key of the pass.  (Uncontested cells -- most -- cost the one atomic they always did.)
+                const uint64_t my_key = t.nv_key[nid], old_key = t.nv_key[old];
+                const uint32_t best = old_key > my_key ? old : (uint32_t)nid;
+                const uint64_t best_key = old_key > my_key ? old_key : my_key;
+                uint32_t cur = max(old, (uint32_t)nid);  // what the atomicMax left behind
+                for (int spin = 0; spin < kMaxSpin; ++spin) {
+                    if (cur == best || t.nv_key[cur] >= best_key) break;  // (every value the cell takes in this pass is an id of this pass)
+                    const uint32_t seen = atomicCAS(&t.pre_dep[slot], cur, best);
+                    if (seen == cur) break;
+                    cur = seen;
+                }
+            }
         }
     }
     __shared__ TileReserveScratch<kRegTiles> trs;

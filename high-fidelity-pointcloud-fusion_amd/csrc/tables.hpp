@@ -164,6 +164,39 @@ HFPF_HD void key_coords(const GridParams& g, uint64_t k, int32_t& x, int32_t& y,
     y = (int32_t)((k >> g.key_sy) & ((1ull << (g.key_sx - g.key_sy)) - 1ull));
     z = (int32_t)(k & ((1ull << g.key_sy) - 1ull));
 }
+// Z-order (Morton) code of a cell: the order the candidates of a clean pass are numbered in (HFPF_MORTON_IDS).  Records of one brick
+// -- 8 x 8 x 8 cells = the low 9 bits of the code -- get consecutive ids, so whatever reads or updates records by id (the per-brick
+// flush of k_update_cells, the registration walk, the dependant-table fill) touches neighbouring lines.  21 bits per axis.
+#ifndef HFPF_MORTON_IDS
+#define HFPF_MORTON_IDS 1
+#endif
+HFPF_HD uint64_t morton_spread(uint32_t v)
+{
+    uint64_t x = v & 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+HFPF_HD uint32_t morton_compact(uint64_t x)
+{
+    x &= 0x1249249249249249ull;
+    x = (x | (x >> 2)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x >> 4)) & 0x100F00F00F00F00Full;
+    x = (x | (x >> 8)) & 0x1F0000FF0000FFull;
+    x = (x | (x >> 16)) & 0x1F00000000FFFFull;
+    x = (x | (x >> 32)) & 0x1FFFFFull;
+    return (uint32_t)x;
+}
+HFPF_HD uint64_t morton_key(int32_t x, int32_t y, int32_t z) { return (morton_spread((uint32_t)x) << 2) | (morton_spread((uint32_t)y) << 1) | morton_spread((uint32_t)z); }
+HFPF_HD void morton_coords(uint64_t k, int32_t& x, int32_t& y, int32_t& z)
+{
+    x = (int32_t)morton_compact(k >> 2);
+    y = (int32_t)morton_compact(k >> 1);
+    z = (int32_t)morton_compact(k);
+}
 HFPF_HD uint32_t brick_index(const GridParams& g, int32_t x, int32_t y, int32_t z)
 {
     return ((uint32_t)(x >> kBrickShift) * (uint32_t)g.bdim[1] + (uint32_t)(y >> kBrickShift)) * (uint32_t)g.bdim[2] +
