@@ -222,9 +222,10 @@ __device__ __forceinline__ void direct_forms(const GridParams& g, const Tables& 
     }
 }
 
-// Waves per SIMD: the tile loop is a chain of dependent table round trips, so resident waves are what hides them.  The binned form
-// (direct forms moved out to k_integrate_overflow) needs 59 VGPRs and runs eight waves per SIMD; asking the compiler for eight shrinks its
-// SGPR budget (94 -> 78, 51 spills instead of 37), so the bound stays at seven.  The un-binned form fits seven (<= 72 VGPRs, no scratch).
+// Waves per SIMD: the tile loop is a chain of dependent table round trips, so resident waves are what hides them.  Seven for both
+// forms.  The binned one (direct forms moved out to k_integrate_overflow) needs only 59 VGPRs, but 94 SGPRs a wave keep it at seven
+// workgroups per CU all the same; asking the compiler for eight shrinks its SGPR budget (94 -> 78, 51 spills instead of 37) for
+// nothing.  The un-binned form fits seven in 72 VGPRs without scratch.
 #ifndef HFPF_INT_WAVES
 #define HFPF_INT_WAVES 7
 #endif
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
         if constexpr (BIN) {
             // The rare lane whose bin region was full or unplanned: handed, with what the direct forms need, to k_integrate_overflow,
             // which runs behind this kernel.  Keeping the direct forms out of the tile loop halves the scalar state this kernel
-            // spills into VGPR lanes (60 -> 30 SGPRs) and frees 19 VGPRs (eight waves per SIMD).
+            // spills into VGPR lanes (60 -> 37 SGPRs) and 13 VGPRs, and no wave waits in the loop for a lane that walks a dependant list.
             const unsigned long long oi = wave_reserve(&t.ctr[C_OVF], todo);
             if (todo) {
                 if (oi < t.ovf_cap) {
@@ -1388,6 +1389,7 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
     const uint32_t step_idx = (uint32_t)(blk_first / per_step);
     const int i = (int)step_idx - g.K;
     uint32_t slot_[kRegTiles], nid_[kRegTiles];
+    uint64_t my_key_[kRegTiles];
     uint32_t f_occ = 0, f_new = 0, f_chg = 0;
 #pragma unroll
     for (int tt = 0; tt < kRegTiles; tt++) {
@@ -1395,8 +1397,10 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         bool want = r < n_cand && step_idx < steps;
         uint64_t nid = 0;
         int32_t xx = 0, yy = 0, zz = 0;
+        my_key_[tt] = 0;
         if (want) {
             nid = base + r + 1;
+            my_key_[tt] = t.nv_key[nid];  // (coalesced, with the record's other fields: a contest further down then costs one dependent read)
             const F3 c = F3{t.nv_c[3 * nid], t.nv_c[3 * nid + 1], t.nv_c[3 * nid + 2]};
             const F3 n = F3{t.nv_n[3 * nid], t.nv_n[3 * nid + 1], t.nv_n[3 * nid + 2]};
             const F3 nb = line_step(g, c, n, i);  // grid.hpp:405
@@ -1425,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
                 // told this lane whom it met; the lane now sees to it that the cell holds a key at least as large as the better of the
                 // two.  Whoever displaces a holder learns of it the same way and takes over that duty, so once every registrant is
                 // through, the cell holds the largest key of the pass.  (Uncontested cells -- most -- cost the one atomic they always did.)
-                const uint64_t my_key = t.nv_key[nid], old_key = t.nv_key[old];
+                const uint64_t my_key = my_key_[tt], old_key = t.nv_key[old];
                 const uint32_t best = old_key > my_key ? old : (uint32_t)nid;
                 const uint64_t best_key = old_key > my_key ? old_key : my_key;
                 uint32_t cur = max(old, (uint32_t)nid);  // what the atomicMax left behind
