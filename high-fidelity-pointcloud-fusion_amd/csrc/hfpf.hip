@@ -177,6 +177,10 @@ struct hfpf_handle {
     Tables t;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host-frame uploads, overlapped with the kernels of earlier frames
+    // ... of ring slots 1, 2, ... modulo n_copy_streams: uploads in flight side by side keep the link busy across the gap between two copies
+    // of one stream (HFPF_COPY_STREAMS=1..4)
+    hipStream_t copy_more[3] = {nullptr, nullptr, nullptr};
+    int n_copy_streams = 2;
     std::string err;
     std::vector<void*> allocs;
     uint64_t device_bytes = 0;
@@ -331,6 +335,14 @@ uint64_t bin_pool_entries(const hfpf_handle* h, uint64_t pts, uint64_t bricks)
 {
     const double per_point = 2.0 * std::max(1.5, (double)h->bin_slack) + 0.125;
     return (uint64_t)(per_point * (double)pts) + 128ull * (bricks + 1);
+}
+
+hipError_t sync_copy_streams(hfpf_handle* h)
+{
+    hipError_t e = hipStreamSynchronize(h->copy_stream);
+    for (hipStream_t cs : h->copy_more)
+        if (cs && e == hipSuccess) e = hipStreamSynchronize(cs);
+    return e;
 }
 
 int scratch(hfpf_handle* h, DevBuf& b, size_t bytes)
@@ -1393,6 +1405,8 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         if (h->h_log_ctr) (void)hipHostFree(h->h_log_ctr);
         if (h->mbox) (void)hipHostFree(h->mbox);
         if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+        for (hipStream_t cs : h->copy_more)
+            if (cs) (void)hipStreamDestroy(cs);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         delete h;
         return rc;
@@ -1406,6 +1420,9 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e)));
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
     if ((e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+    if (const char* cs = getenv("HFPF_COPY_STREAMS")) h->n_copy_streams = std::max(1, std::min(atoi(cs), 4));
+    for (int k = 0; k + 1 < h->n_copy_streams; k++)
+        if ((e = hipStreamCreateWithFlags(&h->copy_more[k], hipStreamNonBlocking)) != hipSuccess) return bail(fail(h, HFPF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
     if ((e = hipHostMalloc((void**)&h->h_ctr, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail(fail(h, HFPF_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)));
     memset(h->h_ctr, 0, C_COUNT * sizeof(unsigned long long));
@@ -1503,6 +1520,11 @@ int hfpf_destroy(hfpf_handle* h)
         (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamDestroy(h->copy_stream);
     }
+    for (hipStream_t cs : h->copy_more)
+        if (cs) {
+            (void)hipStreamSynchronize(cs);
+            (void)hipStreamDestroy(cs);
+        }
     for (auto& pr : h->ev_pending) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -1613,7 +1635,7 @@ static int integrate_host_locked(hfpf_handle* h, const void* base, bool bounce, 
     }
     if (h->ring_cap < bytes) {  // (re)size the ring: nothing may be in flight in it
         if ((rc = flush_pending_locked(h))) return rc;
-        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        HIPCHK(h, sync_copy_streams(h));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (auto& f : h->fslot) f.pending = false;
         if (h->ring_d) {
@@ -1649,8 +1671,10 @@ static int integrate_host_locked(hfpf_handle* h, const void* base, bool bounce, 
         host_copy(h, f.h, base, bytes);
         src = f.h;
     }
-    HIPCHK(h, hipMemcpyAsync((char*)h->ring_d + (size_t)slot * h->ring_cap, src, bytes, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(h, hipEventRecord(f.copied, h->copy_stream));
+    const uint32_t which = slot % (uint32_t)h->n_copy_streams;
+    hipStream_t cs = which ? h->copy_more[which - 1] : h->copy_stream;
+    HIPCHK(h, hipMemcpyAsync((char*)h->ring_d + (size_t)slot * h->ring_cap, src, bytes, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipEventRecord(f.copied, cs));
     if (h->pend_n == 0) {
         h->pend_first = slot;
         h->pend_pts = n_points;
@@ -1713,7 +1737,7 @@ int hfpf_host_free(hfpf_handle* h, void* host_ptr)
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
-    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    HIPCHK(h, sync_copy_streams(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipHostFree(host_ptr));
     return HFPF_OK;
