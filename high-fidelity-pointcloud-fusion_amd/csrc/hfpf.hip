@@ -46,9 +46,9 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
-struct StageSlot {  // pose / frame-id staging for one in-flight integrate call
+struct StageSlot {  // pose / frame-id staging for one in-flight integrate call: n poses (12 doubles each), then n frame ids -- ONE upload
     double* h_pose = nullptr;
-    uint32_t* h_ids = nullptr;
+    uint32_t* h_ids = nullptr;  // = h_pose + 12 * (frames of the call)
     double* d_pose = nullptr;
     uint32_t* d_ids = nullptr;
     uint32_t cap = 0;
@@ -254,7 +254,7 @@ struct hfpf_handle {
     uint64_t n_bricks_before = 0; // ... and at the read-back before the count last changed
     bool bin_spare = true;        // HFPF_BIN_SPARE=0: no bin regions for bricks the launch discovers
     float test_bin_scale = 1.f;   // tests only (HFPF_TEST_BIN_SCALE): shrinks the planned bin regions so that they overflow into the direct forms
-    DevBuf bin_pt_buf, bin_rgb_buf;
+    DevBuf bin_pt_buf, bin_rgb_buf, bin_sums;
     DevBuf ovf_pt_buf, ovf_aux_buf;  // overflow list of one integrate launch (points that found no room in a bin)
 
     // multi-GPU: RCCL is resolved at run time so a single-GPU user needs no librccl
@@ -271,6 +271,7 @@ struct hfpf_handle {
     bool timing = false;
     bool timing_detail = false;  // hfpf_kernel_timing(h, 2): also one event pair per kernel of an integrate call (ids 2..4)
     std::vector<hipEvent_t> ev_detail;  // 4 events per call: before k_integrate, after it, after k_update*, after k_buffer
+    std::vector<uint8_t> ev_detail_ran;  // per call: bit k = the kernel between events k and k + 1 was launched
     double t_detail_ms[3] = {0, 0, 0};
     uint64_t n_detail[3] = {0, 0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
@@ -458,7 +459,7 @@ int check_device_errors(hfpf_handle* h)
     if (e & E_REG) what += " registrations (max_normals*7)";
     if (e & E_DEP) what += " dependant table";
     if (e & E_SPIN) what += " brick-claim spin bound";
-    if (e & E_DEPCNT) what += " >65535 dependants on one cell";
+    if (e & E_DEPCNT) what += " more than 65535 dependants on one cell";
     if (e & E_FRAME) what += " frame id >= max_frames";
     if (e & E_OVF) what += " integrate overflow list";
     return fail(h, HFPF_ERR_CAPACITY, "device pool overflow:%s", what.c_str());
@@ -709,17 +710,17 @@ int acquire_stage(hfpf_handle* h, uint32_t n_frames, StageSlot** out)
     if (s.cap < n_frames) {
         if (s.h_pose) {
             HIPCHK(h, hipHostFree(s.h_pose));
-            HIPCHK(h, hipHostFree(s.h_ids));
             HIPCHK(h, hipFree(s.d_pose));
-            HIPCHK(h, hipFree(s.d_ids));
+            s.h_pose = nullptr, s.d_pose = nullptr, s.cap = 0;
         }
         const uint32_t cap = std::max<uint32_t>(n_frames, 64);
-        HIPCHK(h, hipHostMalloc((void**)&s.h_pose, (size_t)cap * 12 * sizeof(double), hipHostMallocDefault));
-        HIPCHK(h, hipHostMalloc((void**)&s.h_ids, (size_t)cap * sizeof(uint32_t), hipHostMallocDefault));
-        HIPCHK(h, hipMalloc((void**)&s.d_pose, (size_t)cap * 12 * sizeof(double)));
-        HIPCHK(h, hipMalloc((void**)&s.d_ids, (size_t)cap * sizeof(uint32_t)));
+        const size_t bytes = (size_t)cap * (12 * sizeof(double) + sizeof(uint32_t));
+        HIPCHK(h, hipHostMalloc((void**)&s.h_pose, bytes, hipHostMallocDefault));
+        HIPCHK(h, hipMalloc((void**)&s.d_pose, bytes));
         s.cap = cap;
     }
+    s.h_ids = reinterpret_cast<uint32_t*>(s.h_pose + 12 * (size_t)n_frames);
+    s.d_ids = reinterpret_cast<uint32_t*>(s.d_pose + 12 * (size_t)n_frames);
     *out = &s;
     return HFPF_OK;
 }
@@ -761,8 +762,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         s->h_ids[f] = id;
     }
     if (!frame_ids) h->next_frame_id += n_frames;
-    HIPCHK(h, hipMemcpyAsync(s->d_pose, s->h_pose, (size_t)n_frames * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(s->d_ids, s->h_ids, (size_t)n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->d_pose, s->h_pose, (size_t)n_frames * (12 * sizeof(double) + sizeof(uint32_t)), hipMemcpyHostToDevice, h->stream));  // poses + ids
 
     const FrameLayout lay{point_step, off_x, off_y, off_z, off_rgb};
     const bool packed = point_step == 16 && off_x == 0 && off_y == 4 && off_z == 8 && off_rgb == 12 && ((uintptr_t)dev_base & 15) == 0 &&
@@ -801,8 +801,9 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         const uint32_t log_rot = 0;
         const dim3 pgrid((unsigned)std::min<uint64_t>((uint64_t)blocks_for(n_points, 256) * launch_frames, (uint64_t)h->integrate_grid));
 #define HFPF_LAUNCH_PROBE(P, C)                                                                                                                    \
-    hipLaunchKernelGGL((k_integrate<P, C, true>), pgrid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, \
-                       lay, (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w, log_rot, probe)
+    hipLaunchKernelGGL((k_integrate<P, C, true>), pgrid, block, 0, h->stream,                                                                        \
+                       IntegrateArgs{h->g, h->t}, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, lay, (const double*)s->d_pose, \
+                       (const uint32_t*)s->d_ids, row_w, log_rot, probe)
         if (packed && !color) HFPF_LAUNCH_PROBE(true, false);
         else if (packed && color) HFPF_LAUNCH_PROBE(true, true);
         else if (!color) HFPF_LAUNCH_PROBE(false, false);
@@ -861,24 +862,37 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
             const float scale = (float)((double)pts / std::max(1.0, h->bin_prev_points)) * h->test_bin_scale;
             const uint32_t n_regions = 2u * (nb_known + 1u);  // two per brick: cells with / without a normal
             const uint32_t n_planned = 2u * (nb + 1u);        // ... and the spare ones behind them
-            hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(n_planned, 256)), dim3(256), 0, h->stream, h->t, n_regions, n_planned, spare_cap, scale,
-                               h->bin_from_probe ? std::max(1.5f, h->bin_slack) : h->bin_slack);
-            h->bin_from_probe = false;
-            size_t bytes = 0;
-            HIPCHK(h, rocprim::exclusive_scan(nullptr, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_planned, rocprim::plus<uint32_t>(), h->stream));
-            int rc2 = scratch(h, h->sort_tmp, bytes);
-            if (rc2) return rc2;
-            bytes = h->sort_tmp.bytes;
-            HIPCHK(h, rocprim::exclusive_scan(h->sort_tmp.p, bytes, h->t.bin_capb, h->t.bin_off, 0u, (size_t)n_planned, rocprim::plus<uint32_t>(), h->stream));
             const uint32_t all_regions = 2u * (uint32_t)(h->t.max_bricks + 2);
-            hipLaunchKernelGGL(k_bin_clamp, dim3(blocks_for(all_regions, 256)), dim3(256), 0, h->stream, h->t, n_planned, all_regions, h->bin_pool);
+            int rc2 = scratch(h, h->bin_sums, (size_t)blocks_for(all_regions, kBinPlanTile) * sizeof(uint32_t));
+            if (rc2) return rc2;
+            hipLaunchKernelGGL(k_bin_plan, dim3(blocks_for(n_planned, kBinPlanTile)), dim3(256), 0, h->stream, h->t, n_regions, n_planned, spare_cap, scale,
+                               h->bin_from_probe ? std::max(1.5f, h->bin_slack) : h->bin_slack, (uint32_t*)h->bin_sums.p);
+            h->bin_from_probe = false;
+            hipLaunchKernelGGL(k_bin_place, dim3(blocks_for(all_regions, kBinPlanTile)), dim3(256), 0, h->stream, h->t, n_planned, all_regions, h->bin_pool,
+                               (const uint32_t*)h->bin_sums.p);
         } else {  // no plan yet: no region exists, every lane takes the direct forms, the demand is recorded
-            HIPCHK(h, hipMemsetAsync(&h->t.ctr[C_OVF], 0, sizeof(unsigned long long), h->stream));  // (k_bin_clamp does this where there is a plan)
+            HIPCHK(h, hipMemsetAsync(&h->t.ctr[C_OVF], 0, sizeof(unsigned long long), h->stream));  // (k_bin_place does this where there is a plan)
             HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
             HIPCHK(h, hipMemsetAsync(h->t.bin_capb, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
         }
     }
     const uint32_t log_rot = (uint32_t)((h->launch_seq++ * 17u) & (kLogRegions - 1));
+    // Detail timing: four events per call and one byte saying which of the three kernels between them ran.  A call that leaves
+    // early gives its events back, so the records stay aligned.
+    struct DetailGuard {
+        hfpf_handle* h;
+        size_t first;
+        bool done = false;
+        ~DetailGuard()
+        {
+            if (done) return;
+            while (h->ev_detail.size() > first) {
+                h->ev_free.push_back(h->ev_detail.back());
+                h->ev_detail.pop_back();
+            }
+        }
+    } detail_guard{h, h->ev_detail.size()};
+    uint8_t detail_ran = 1;  // k_integrate (+ its overflow kernel) always runs
     auto detail_mark = [&]() -> hipError_t {  // per-kernel boundaries of this call (detail timing only)
         if (!h->timing_detail) return hipSuccess;
         hipEvent_t e = nullptr;
@@ -893,8 +907,9 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     };
     HIPCHK(h, detail_mark());
 #define HFPF_LAUNCH_INTEGRATE(P, C, B)                                                                                                              \
-    hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream, h->g, h->t, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, lay, \
-                       (const double*)s->d_pose, (const uint32_t*)s->d_ids, row_w, log_rot, probe)
+    hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream,                                                                           \
+                       IntegrateArgs{h->g, h->t}, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, lay, (const double*)s->d_pose, \
+                       (const uint32_t*)s->d_ids, row_w, log_rot, probe)
     if (!bin) {
         if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, false);
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, false);
@@ -914,6 +929,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         HIPCHK(h, detail_mark());
         if (have_plan) {
             if (h->h_ctr[C_NORMALS] > 0 || h->normals_possible) {  // without a normal record no cell has dependants
+                detail_ran |= 2;
                 if (h->update_cells) {
                     const int shape = pick_update_shape(h, (double)n_points * n_frames, nb);
 #define HFPF_LAUNCH_UPDATE(C, S) \
@@ -929,6 +945,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
                 }
             }
             HIPCHK(h, detail_mark());
+            detail_ran |= 4;
             if (color) hipLaunchKernelGGL(k_buffer<true>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
             else hipLaunchKernelGGL(k_buffer<false>, dim3(nb), dim3(256), 0, h->stream, h->g, h->t, nb);
             HIPCHK(h, detail_mark());
@@ -941,6 +958,8 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     }
 #undef HFPF_LAUNCH_INTEGRATE
     HIPCHK(h, hipGetLastError());
+    if (h->timing_detail) h->ev_detail_ran.push_back(detail_ran);
+    detail_guard.done = true;
     if (h->timing) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
         h->ev_pending.emplace_back(e0, e1);
@@ -981,17 +1000,18 @@ int resolve_timing(hfpf_handle* h)
         h->ev_free.push_back(pr.second);
     }
     h->ev_pending.clear();
-    for (size_t i = 0; i + 3 < h->ev_detail.size(); i += 4) {
+    for (size_t c = 0; 4 * c + 3 < h->ev_detail.size() && c < h->ev_detail_ran.size(); c++) {
         for (int k = 0; k < 3; k++) {
+            if (!(h->ev_detail_ran[c] & (1u << k))) continue;  // not launched in this call (e.g. no dependants yet: no k_update_cells)
             float ms = 0.f;
-            HIPCHK(h, hipEventElapsedTime(&ms, h->ev_detail[i + k], h->ev_detail[i + k + 1]));
-            if (ms < 0.02f) continue;  // the kernel did not run in this call (no dependants yet: no k_update_cells)
+            HIPCHK(h, hipEventElapsedTime(&ms, h->ev_detail[4 * c + k], h->ev_detail[4 * c + k + 1]));
             h->t_detail_ms[k] += (double)ms;
             h->n_detail[k]++;
         }
     }
     for (hipEvent_t e : h->ev_detail) h->ev_free.push_back(e);
     h->ev_detail.clear();
+    h->ev_detail_ran.clear();
     return HFPF_OK;
 }
 
@@ -1492,15 +1512,13 @@ int hfpf_destroy(hfpf_handle* h)
     for (DevBuf* b : {&h->sort_tmp, &h->keys_a, &h->keys_b, &h->vals_a, &h->vals_b, &h->rows_dev, &h->probe_a, &h->probe_b, &h->probe_c, &h->probe_d,
                       &h->probe_e, &h->probe_f})
         if (b->p) (void)hipFree(b->p);
-    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->bin_pt_buf, &h->bin_rgb_buf, &h->ovf_pt_buf, &h->ovf_aux_buf, &h->pend_a, &h->pend_b})
+    for (DevBuf* b : {&h->ex_send, &h->ex_recv, &h->ex_counts, &h->stats_total, &h->bin_pt_buf, &h->bin_rgb_buf, &h->bin_sums, &h->ovf_pt_buf, &h->ovf_aux_buf, &h->pend_a, &h->pend_b})
         if (b->p) (void)hipFree(b->p);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t_)h->comm);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     for (auto& s : h->stage) {
         if (s.h_pose) (void)hipHostFree(s.h_pose);
-        if (s.h_ids) (void)hipHostFree(s.h_ids);
         if (s.d_pose) (void)hipFree(s.d_pose);
-        if (s.d_ids) (void)hipFree(s.d_ids);
         if (s.done) (void)hipEventDestroy(s.done);
     }
     delete h->stage_pool;
@@ -1589,9 +1607,17 @@ static int flush_pending_locked(hfpf_handle* h)
     if (h->pend_n == 0) return HFPF_OK;
     const uint32_t first = h->pend_first, n = h->pend_n;
     h->pend_n = 0;
-    if (h->poisoned) return HFPF_OK;  // the handle refuses work until hfpf_clear: the frames are dropped like any later one
-    FrameSlot& last = h->fslot[first + n - 1];
-    HIPCHK(h, hipStreamWaitEvent(h->stream, last.copied, 0));  // the copy stream is in order: the earlier uploads are done too
+    // the handle refuses work until hfpf_clear: frames accepted before the failure surfaced are dropped, and the caller is told
+    if (h->poisoned) return fail(h, HFPF_ERR_STATE, "%u accepted host frame(s) dropped: handle failed earlier (%s); hfpf_clear resets it", n, h->poison_msg.c_str());
+    // The slots of a batch alternate over the copy streams (slot % n_copy_streams): the kernels wait for the LAST upload of every
+    // stream that carried one of them -- a stream is in order, so its earlier uploads are done too.  (f.done, recorded behind the
+    // kernels below, then also means "this slot's upload has left its pinned bounce buffer".)
+    for (uint32_t k = n, seen = 0; k-- > 0;) {
+        const uint32_t which = (first + k) % (uint32_t)h->n_copy_streams;
+        if (seen & (1u << which)) continue;
+        seen |= 1u << which;
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->fslot[first + k].copied, 0));
+    }
     int rc = integrate_device_locked(h, (const char*)h->ring_d + (size_t)first * h->ring_cap, n, h->ring_cap, h->pend_pts, h->pend_lay[0], h->pend_lay[1],
                                      h->pend_lay[2], h->pend_lay[3], h->pend_lay[4], h->pend_pose, nullptr);
     if (rc) return rc;
@@ -1754,9 +1780,13 @@ int hfpf_clean(hfpf_handle* h)
 {
     if (!h) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
-    const int pre = check_usable(h);
+    // Everything that can fail in front of the collectives of a distributed clean is folded into `pre`: a rank whose device
+    // cannot be selected or whose deferred host-frame launch fails (scratch allocation, frame id >= max_frames, HIP error) still
+    // enters the status gather of clean_locked, so its peers leave with HFPF_ERR_DIST instead of waiting in ncclAllGather for ever.
+    int pre = HFPF_OK;
+    if (hipError_t e_ = hipSetDevice(h->cfg.device)) pre = fail(h, HFPF_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e_));
+    if (!pre) pre = poison_on_error(h, flush_pending_locked(h));  // host frames still waiting for their launch
+    if (!pre) pre = check_usable(h);
     if (pre && !h->dist_on) return pre;
     if (!h->timing || pre) return poison_on_error(h, clean_locked(h, pre));
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1860,12 +1890,14 @@ int hfpf_extract_filtered(hfpf_handle* h, const hfpf_extract_opts* opts, hfpf_ro
     if (!h || !rows || !n_rows) return HFPF_ERR_BAD_ARG;
     if (opts && opts->struct_size != sizeof(hfpf_extract_opts)) return HFPF_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(h->mtx);
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (int rcf = flush_pending_locked(h)) return rcf;  // host frames still waiting for their launch
     *rows = nullptr;
     *n_rows = 0;
     Tables& t = h->t;
-    int rc = check_usable(h);
+    // (as in hfpf_clean: a local failure in front of the collective travels through the status gather, it does not skip it)
+    int rc = HFPF_OK;
+    if (hipError_t e_ = hipSetDevice(h->cfg.device)) rc = fail(h, HFPF_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e_));
+    if (!rc) rc = poison_on_error(h, flush_pending_locked(h));  // host frames still waiting for their launch
+    if (!rc) rc = check_usable(h);
     if (!rc) rc = read_counters(h);
     if (!rc) rc = poison_on_error(h, check_device_errors(h));
     if (rc && !h->dist_on) return rc;
@@ -2224,6 +2256,7 @@ int hfpf_get_counters(hfpf_handle* h, hfpf_counters* out)
     out->replay_members = c[C_REPLAY_MEMBER];
     out->points_direct = c[C_BUFFERED];
     out->table_misses = c[C_TABLE_MISS];
+    out->update_extra_rounds = c[C_UPD_ROUNDS];
     return HFPF_OK;
 }
 

@@ -222,6 +222,27 @@ __device__ __forceinline__ void direct_forms(const GridParams& g, const Tables& 
     }
 }
 
+// Grid constants and table descriptor of k_integrate as ONE struct and its FIRST argument, so that a field's place in the kernarg
+// segment is offsetof(IntegrateArgs, field).  (The frame, pose and frame-id pointers stay separate __restrict__ arguments: that
+// is what lets the compiler read the wave-uniform pose with scalar loads.)
+struct IntegrateArgs {
+    GridParams g;
+    Tables t;
+};
+// The table descriptor as the RARE paths of the tile loop see it (a new brick, a newly occupied cell's list flush, a point
+// without room in its bin, the one lane a frame that files the viewpoint): read from the kernarg segment where it is needed.
+// The compiler treats by-value kernel arguments as loop invariants and keeps every field the loop mentions anywhere in scalar
+// registers for its whole length -- some forty table bases and limits here, 37 of which it then parked in VGPR lanes, with a
+// v_readlane / v_writelane wherever the tile body wanted one back.  The empty asm hides where the pointer comes from, so the
+// scalar loads behind it stay inside the branch they are written in.
+typedef const __attribute__((address_space(4))) char* kernarg_ptr;
+__device__ __forceinline__ const Tables& kernarg_tables()
+{
+    kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const Tables*)(p + offsetof(IntegrateArgs, t));
+}
+
 // Waves per SIMD: the tile loop is a chain of dependent table round trips, so resident waves are what hides them.  Seven for both
 // forms.  The binned one (direct forms moved out to k_integrate_overflow) needs only 59 VGPRs, but 94 SGPRs a wave keep it at seven
 // workgroups per CU all the same; asking the compiler for eight shrinks its SGPR budget (94 -> 78, 51 spills instead of 37) for
@@ -233,12 +254,14 @@ __device__ __forceinline__ void direct_forms(const GridParams& g, const Tables& 
 #define HFPF_INT_WAVES_BIN 7
 #endif
 template <bool PACKED16, bool COLOR, bool BIN>
-__global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) void k_integrate(const GridParams g, const Tables t, const uint8_t* __restrict__ frames,
+__global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) void k_integrate(const IntegrateArgs A, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
                                                    const uint32_t* __restrict__ frame_ids, const uint32_t row_w, const uint32_t log_rot,
                                                    const uint32_t probe)
 {
+    const GridParams& g = A.g;
+    const Tables& t = A.t;
     // probe != 0: dry run of the batch's first frames for a session that has no bin plan yet -- transform, index, claim the
     // bricks and record the per-region demand; nothing else is touched (the frames come again in the real launch).
     __shared__ unsigned long long queue[4][kQueueRows * kQueueStride];
@@ -298,9 +321,10 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
         for (int k = 0; k < 12; k++) T[k] = poses[12 * f + k];
         const uint32_t fid = frame_ids[f];
         if (i == 0) {  // viewpoint = float(translation), node.cpp:290
-            t.frame_vp[3 * (uint64_t)fid + 0] = (float)T[3];
-            t.frame_vp[3 * (uint64_t)fid + 1] = (float)T[7];
-            t.frame_vp[3 * (uint64_t)fid + 2] = (float)T[11];
+            float* vp = (BIN ? kernarg_tables() : t).frame_vp + 3 * (uint64_t)fid;
+            vp[0] = (float)T[3];
+            vp[1] = (float)T[7];
+            vp[2] = (float)T[11];
         }
         const uint8_t* __restrict__ base = frames + (uint64_t)f * frame_stride;
         bool act = i < n_pts;
@@ -347,7 +371,7 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
                 m &= ~sm;
             }
         }
-        const uint32_t b = BIN ? brick_acquire_groups(t, bidx, act, dir_word, same_brick) : brick_acquire_wave(t, bidx, act, dir_word);
+        const uint32_t b = BIN ? brick_acquire_groups(t, bidx, act, dir_word, same_brick, true) : brick_acquire_wave(t, bidx, act, dir_word);
         act = act && b != 0;
         const uint32_t lcell = local_index(ix, iy, iz);
         const uint32_t slot = b * kBrickCells + lcell;
@@ -379,7 +403,7 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
             const unsigned long long fm = __ballot(first);
             if (fm) {
                 if (occ_n + 64u > (uint32_t)kOccStage) {
-                    flush_occ_stage(t, s_occ, occ_n);
+                    flush_occ_stage(BIN ? kernarg_tables() : t, s_occ, occ_n);
                     occ_n = 0;
                 }
                 if (first) s_occ[occ_n + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = slot;
@@ -432,13 +456,14 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
             // The rare lane whose bin region was full or unplanned: handed, with what the direct forms need, to k_integrate_overflow,
             // which runs behind this kernel.  Keeping the direct forms out of the tile loop halves the scalar state this kernel
             // spills into VGPR lanes (60 -> 37 SGPRs) and 13 VGPRs, and no wave waits in the loop for a lane that walks a dependant list.
-            const unsigned long long oi = wave_reserve(&t.ctr[C_OVF], todo);
+            const Tables& tr = kernarg_tables();
+            const unsigned long long oi = wave_reserve(&tr.ctr[C_OVF], todo);
             if (todo) {
-                if (oi < t.ovf_cap) {
-                    t.ovf_pt[oi] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
-                    t.ovf_aux[oi] = make_uint2(fid | (has_n ? kOvfHasNormal : 0u) | (has_d ? kOvfHasDeps : 0u), rgb);
+                if (oi < tr.ovf_cap) {
+                    tr.ovf_pt[oi] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
+                    tr.ovf_aux[oi] = make_uint2(fid | (has_n ? kOvfHasNormal : 0u) | (has_d ? kOvfHasDeps : 0u), rgb);
                 } else {
-                    atomicOr(&t.ctr[C_ERR], (unsigned long long)E_OVF);  // (the list holds a whole launch: cannot happen)
+                    atomicOr(&tr.ctr[C_ERR], (unsigned long long)E_OVF);  // (the list holds a whole launch: cannot happen)
                 }
             }
         } else {
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
 // for a whole launch, so a session without a bin plan (its first small batch) comes through here entirely.  A workgroup takes 256
 // points at a time: one lane per point for the buffering, then one lane per (point, dependant) PAIR -- the pairs of the 256 points
 // are numbered through a prefix sum of the list lengths, so a point on a cell with twenty dependants does not hold its wave for
-// twenty dependent reads.  The list is reset by the next launch's bin plan (k_bin_clamp; the host where there is no plan).
+// twenty dependent reads.  The list is reset by the next launch's bin plan (k_bin_place; the host where there is no plan).
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_integrate_overflow(const GridParams g, const Tables t, const uint32_t log_rot)
 {
@@ -814,8 +839,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
     if (tid < 3) blk_ctr[tid] = 0;
     const float4* __restrict__ dep4 = reinterpret_cast<const float4*>(t.dep);
     uint32_t c_tested = 0, c_member = 0, c_miss = 0;
-    // Software pipeline: the points of round r+1 are read from the bin while round r's items are worked, and an item's dependant
-    // entry is read one item ahead (the first one of a round ahead of the scatter).
+    // Software pipeline: the points of round r+1 are read from the bin while round r's items are worked (without it the streaming
+    // replay, whose bricks take several rounds, is a third slower), and an item's dependant entry is read one item ahead (the first
+    // one of a round ahead of the scatter).
     float4 pt[PER];
     uint32_t col[PER];
     auto load_round = [&](uint32_t r0) {
@@ -873,10 +899,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
         it.p_lo = ch * CH;
         it.p_hi = min(n_c, it.p_lo + CH);
     };
-    load_round(0);
+    load_round(0);  // in flight while the tables above are cleared
     __syncthreads();
     for (uint32_t r0 = 0; r0 < fill; r0 += (uint32_t)kUpd2Cap) {  // block-uniform trip count
         const uint32_t n_round = min((uint32_t)kUpd2Cap, fill - r0);
+
         // 1. rank within the cell from the histogram's returning atomic
         uint32_t rk[PER];
 #pragma unroll
@@ -1028,6 +1055,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
         atomicAdd(&t.log_ctr[(blockIdx.x & (kLogRegions - 1)) * 16 + 2 + tid], (unsigned long long)blk_ctr[tid]);
     }
     if (tid == 2 && blk_ctr[2]) atomicAdd(&t.ctr[C_TABLE_MISS], (unsigned long long)blk_ctr[2]);  // rare by construction
+    if (tid == 3 && fill > (uint32_t)kUpd2Cap) atomicAdd(&t.ctr[C_UPD_ROUNDS], (unsigned long long)((fill - 1u) / (uint32_t)kUpd2Cap));  // (few bricks)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1112,35 +1140,87 @@ __global__ __launch_bounds__(256) void k_buffer(const GridParams g, const Tables
 // Regions [n_regions, n_planned) belong to brick ids the host has not seen yet: ids are handed out in order, so the next bricks a
 // launch discovers find a region of `spare_cap` entries waiting (without one all their points go through the overflow list and
 // take the direct forms).
-__global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_regions, const uint32_t n_planned, const uint32_t spare_cap, const float scale,
-                                                  const float slack)
+// Two launches: k_bin_plan writes the capacities and one sum per workgroup of kBinPlanTile regions; k_bin_place turns them into
+// region offsets (the sums in front of its tile + a scan inside the tile), switches off what does not fit the pool and restarts
+// the demand counters.  (Until round 4: plan, a two-launch library scan, clamp -- four dependent launches of ~5 us in front of
+// every integrate call.)
+constexpr uint32_t kBinPlanTile = 1024;  // regions per workgroup: 256 threads x 4 consecutive regions
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_w)  // sum over a 256-thread workgroup (convergent; s_w: 4 words)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_planned) return;
-    uint32_t cap = 0;
-    if (r >= n_regions) {
-        cap = spare_cap;
-    } else if (r >= 2) {
-        const uint32_t demand = t.bin_fill[r & ~1u] + t.bin_fill[r | 1u];
-        if (demand) cap = (uint32_t)fminf((float)demand * scale * slack, 2.0e9f) + 64u;  // (saturated: a float above 2^32 does not convert)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t r = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(256) void k_bin_plan(const Tables t, const uint32_t n_regions, const uint32_t n_planned, const uint32_t spare_cap, const float scale,
+                                                  const float slack, uint32_t* __restrict__ tile_sums)
+{
+    __shared__ uint32_t s_w[4];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t r = blockIdx.x * kBinPlanTile + threadIdx.x * 4u + k;
+        if (r >= n_planned) continue;
+        uint32_t cap = 0;
+        if (r >= n_regions) {
+            cap = spare_cap;
+        } else if (r >= 2) {
+            const uint32_t demand = t.bin_fill[r & ~1u] + t.bin_fill[r | 1u];
+            if (demand) cap = (uint32_t)fminf((float)demand * scale * slack, 2.0e9f) + 64u;  // (saturated: a float above 2^32 does not convert)
+        }
+        t.bin_capb[r] = cap;
+        sum += cap;
     }
-    t.bin_capb[r] = cap;
+    sum = block_sum_256(sum, s_w);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = sum;
 }
 
-// After the exclusive scan of the capacities: regions that do not fit the pool are switched off, and the demand counters of ALL
-// regions restart -- also those of bricks the host has not heard of yet (claimed since its last counter read-back: they have no
-// region until then and keep recording their demand): left alone, their counters would add up over every launch until the next
-// clean pass and the plan made from them would be inflated by that factor.  With every counter holding ONE launch's demand the
-// planned capacities add up to at most 2 x slack x points + 128 x bricks < the pool size (hfpf.hip bin_pool_entries), so the 32-bit
-// scan cannot wrap.
-__global__ __launch_bounds__(256) void k_bin_clamp(const Tables t, const uint32_t n_regions, const uint32_t all_regions, const uint64_t pool)
+// Offsets, clamp, restart.  Regions that do not fit the pool are switched off, and the demand counters of ALL regions restart --
+// also those of bricks the host has not heard of yet (claimed since its last counter read-back: they have no region until then and
+// keep recording their demand): left alone, their counters would add up over every launch until the next clean pass and the plan
+// made from them would be inflated by that factor.  With every counter holding ONE launch's demand the planned capacities add up
+// to at most 2 x slack x points + 128 x bricks < the pool size (hfpf.hip bin_pool_entries), so the 32-bit sums cannot wrap.
+__global__ __launch_bounds__(256) void k_bin_place(const Tables t, const uint32_t n_planned, const uint32_t all_regions, const uint64_t pool,
+                                                   const uint32_t* __restrict__ tile_sums)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= all_regions) return;
-    // (regions behind the planned ones are off: an earlier launch may have planned more spare regions than this one)
-    if (r >= n_regions || (uint64_t)t.bin_off[r] + t.bin_capb[r] > pool) t.bin_capb[r] = 0;
-    t.bin_fill[r] = 0;
-    if (r == 0) t.ctr[C_OVF] = 0;  // the overflow list of the previous launch has been worked off (k_integrate_overflow)
+    __shared__ uint32_t s_w[4];
+    const uint32_t r0 = blockIdx.x * kBinPlanTile + threadIdx.x * 4u;
+    if (blockIdx.x * kBinPlanTile < n_planned) {  // block-uniform
+        uint32_t before = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) before += tile_sums[b];
+        before = block_sum_256(before, s_w);
+        uint32_t cap[4], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            cap[k] = r0 + k < n_planned ? t.bin_capb[r0 + k] : 0u;
+            mine += cap[k];
+        }
+        const uint32_t incl = wave_inclusive_scan(mine);
+        if ((threadIdx.x & 63u) == 63u) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t off = before + incl - mine;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) off += s_w[w];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t r = r0 + k;
+            if (r < n_planned) {
+                t.bin_off[r] = off;
+                if ((uint64_t)off + cap[k] > pool) t.bin_capb[r] = 0;
+                off += cap[k];
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t r = r0 + k;
+        if (r >= all_regions) continue;
+        if (r >= n_planned) t.bin_capb[r] = 0;  // (an earlier launch may have planned more spare regions than this one)
+        t.bin_fill[r] = 0;
+        if (r == 0) t.ctr[C_OVF] = 0;  // the overflow list of the previous launch has been worked off (k_integrate_overflow)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1743,8 +1823,12 @@ __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const ui
         const uint32_t slot = slot_[tt], old_cnt = old_cnt_[tt], new_cnt = new_cnt_[tt];
         const uint64_t info = info_[tt], old_off = info >> kDepOffShift;
         const unsigned long long off = off_[tt];
-        if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask || old_cnt > kDepOldMax) {  // host falls back to a full (compacting) rebuild
-            atomicOr(&t.ctr[C_ERR], (unsigned long long)((new_cnt > kDepCntMask || old_cnt > kDepOldMax) ? E_DEPCNT : E_DEP));
+        // No room left in dep[], or an old list too long for the 15-bit note of the cursor word (kDepOldMax; the info word itself
+        // counts to 65535): E_DEP, which the host answers with the compacting rebuild (k_dep_*, no such limit).  More than 65535
+        // entries on one cell fit nowhere: E_DEPCNT, a capacity error.  (A cell's registrants all lie within K cells of it along
+        // their normals, a few hundred voxels at most, so neither limit is reachable by a real scene.)
+        if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask || old_cnt > kDepOldMax) {
+            atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
             t.dep_tmp[slot] = kDepPoison;  // k_depinc_fill skips this cell
             continue;
         }

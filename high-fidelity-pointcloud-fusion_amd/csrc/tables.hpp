@@ -74,6 +74,7 @@ enum Ctr : int {
     C_TOUCHED_SINGLE, // host mirror only (sum of word 4 of the striped lines): touched cells of the running pass in single-run bricks
     C_TABLE_MISS,   // work items of k_update_cells that found no slot in the LDS record table (they update HBM directly)
     C_OVF,          // entries in the overflow list of the running integrate launch (k_integrate -> k_integrate_overflow)
+    C_UPD_ROUNDS,   // sort rounds beyond the first that bricks of k_update_cells took (diagnostic: which bricks exceed one LDS round)
     C_COUNT = 32
 };
 
@@ -315,10 +316,14 @@ __device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bo
 // by brick anyway): the first lane of every group claims its brick in ONE pass -- the leaders of different bricks run the claim
 // side by side instead of one after the other -- and hands the id to its group.  No lane waits on another lane of its own wave
 // (leaders hold distinct bricks), only on other waves, as before.
-__device__ inline uint32_t brick_acquire_groups(const Tables& t, uint32_t bidx, bool want, uint32_t v, unsigned long long same_brick)
+// rare_tables: the claim (a rare branch of the caller's loop) reads the table descriptor from the kernarg segment on the spot
+// (kernels.hpp kernarg_tables) instead of keeping the caller's copy of its fields alive across the loop.
+__device__ __forceinline__ const Tables& kernarg_tables();
+__device__ inline uint32_t brick_acquire_groups(const Tables& t_in, uint32_t bidx, bool want, uint32_t v, unsigned long long same_brick, bool rare_tables = false)
 {
     const bool need = want && (v == 0 || v == kLock);
     if (__ballot(need) == 0) return v;
+    const Tables& t = rare_tables ? kernarg_tables() : t_in;
     const uint32_t lane = lane_id();
     const uint32_t leader = want ? (uint32_t)(__ffsll((long long)same_brick) - 1) : lane;
     // a group's lanes read the same directory word, but not necessarily the same value (another wave may publish in between):

@@ -65,7 +65,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "points_presented", "points_zclip_pass", "points_in_bbox", "points_buffered", "dep_pairs_tested",
         "dep_pairs_member", "voxels_occupied", "voxels_with_normal", "bricks_allocated", "registrations",
-        "dep_entries", "frames_integrated", "clean_passes", "device_bytes", "replay_members", "points_direct", "table_misses")]
+        "dep_entries", "frames_integrated", "clean_passes", "device_bytes", "replay_members", "points_direct", "table_misses", "update_extra_rounds")]
 
 
 ROW_DTYPE = np.dtype(

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HFPF_ABI_VERSION 4
+#define HFPF_ABI_VERSION 5
 
 /* hfpf_config.flags */
 #define HFPF_FLAG_FUSE_COLOR 1u /* EXTENSION: also average the member points' RGB per voxel (reference: never, grid.hpp:471-479) */
@@ -111,6 +111,7 @@ typedef struct hfpf_counters {
     uint64_t replay_members;    /* buffered points found inside a cylinder when replayed by a clean pass (grid.hpp:418-440) */
     uint64_t points_direct;     /* of points_buffered: appended one by one through the overflow list (no bin region or a full one), outside the bricks' runs */
     uint64_t table_misses;      /* work items of the dependant update that found no slot in the LDS record table (updated HBM directly) */
+    uint64_t update_extra_rounds; /* (ABI 5) sort rounds beyond the first that bricks of the dependant update / streaming replay took (a brick with more parked points than one LDS round holds) */
 } hfpf_counters;
 
 void hfpf_default_config(hfpf_config* cfg);

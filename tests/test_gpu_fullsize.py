@@ -176,6 +176,62 @@ def test_update_forms_cell_sorted_and_per_point_give_the_same_bits(hfpf_mod, syn
         assert ctr[k] == ctr2[k], k
 
 
+class _TwoEpochScene(scenes.Scene):
+    """`first` frames, a clean pass, the remaining frames, a final clean pass."""
+
+    def __init__(self, first, *a, **kw):
+        super().__init__(*a, **kw)
+        self.first = first
+
+    def schedule(self):
+        for f in range(self.n_frames):
+            yield ("integrate", f)
+            if f + 1 == self.first:
+                yield ("clean",)
+        yield ("clean",)
+
+
+@pytest.mark.slow
+def test_config3_update_shapes_and_colour_vs_oracle_at_scale(oracle_mod, hfpf_mod, synth_mod, monkeypatch):
+    """configs[2]'s production kernels against the ORACLE at its resolution: 2048x1536 frames into the 2 m^3 box @ 0.5 mm
+    -- two frames, a clean pass, then four frames in ONE integrate call, so that the dependant update of that call sees
+    (point, dependant) pairs by the ten million, 200-300 records on a brick and bricks with more parked points than one LDS round
+    of the wide shape holds (`update_extra_rounds`).  Five engine runs: the adaptive shape choice, the dense shape forced, the wide
+    shape forced (HFPF_UPD_SHAPE=1: k_update_cells<false,512,1536,512,1024,6>), and colour fusion under both shapes (the 1024-point
+    colour instantiations) -- each compared with the oracle (which fuses colour when asked), the shapes with each other byte for
+    byte.  Oracle ~20 s for the 18.9 M points."""
+    bbox = (-1.0, 1.0, -0.5, 0.5, 0.0, 1.0)
+    sc = _TwoEpochScene(2, 6, 2048, 1536, 0.0005, bbox=bbox)
+    caps = dict(max_bricks=400000, max_log_points=24 << 20, max_normals=6 << 20, max_frames=64, frame_width=2048)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=bbox, fuse_color=True)
+    ref_c = scenes.run(og, sc, "capture", color=True)
+    oc = og.counters()
+    og.close()
+    ref = ref_c.copy()
+    ref["rgb"] = 0  # the reference's own behaviour: colour never fused (geometry and counts do not depend on the extension)
+    runs = {}
+    for name, shape, color in (("adaptive", None, False), ("dense", "0", False), ("wide", "1", False), ("dense+colour", "0", True),
+                               ("wide+colour", "1", True)):
+        if shape is None:
+            monkeypatch.delenv("HFPF_UPD_SHAPE", raising=False)
+        else:
+            monkeypatch.setenv("HFPF_UPD_SHAPE", shape)
+        rows, ctr, dims = _stream(hfpf_mod, sc, 4, dict(caps, fuse_color=color))
+        assert dims == (3999, 1999, 1999)
+        assert (oc["presented"], oc["zclip_pass"], oc["inserted"], oc["buffered"]) == (
+            ctr["points_presented"], ctr["points_zclip_pass"], ctr["points_in_bbox"], ctr["points_buffered"]), name
+        assert ctr["dep_pairs_tested"] > 1e7, (name, ctr["dep_pairs_tested"])
+        assert ctr["update_extra_rounds"] > 0, "%s: no brick took more than one round" % name
+        scenes.compare_rows(ref_c if color else ref, rows)
+        runs[name] = (rows, ctr)
+    assert len(ref) > 1000000
+    for a, b in (("adaptive", "dense"), ("adaptive", "wide"), ("dense+colour", "wide+colour")):
+        assert runs[a][0].tobytes() == runs[b][0].tobytes(), "%s and %s differ" % (a, b)
+        for k in ("dep_pairs_tested", "dep_pairs_member", "replay_members", "voxels_with_normal"):
+            assert runs[a][1][k] == runs[b][1][k], (a, b, k)
+    assert len(np.unique(runs["wide+colour"][0]["rgb"])) > 1000
+
+
 def test_config4_shared_two_cubic_metre_grid_cameras_vs_oracle(oracle_mod, hfpf_mod, synth_mod):
     """configs[3] shape: one camera per rank (distinct frame and pose seeds), shared 2 m^3 bbox @ 1 mm (1999x999x999 cells), merge
     at every clean.  3 virtual ranks on one device against the oracle fed the union of the cameras' frames in canonical

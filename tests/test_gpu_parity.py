@@ -205,3 +205,53 @@ def test_full_record_table_falls_back_to_device_atomics(oracle_mod, hfpf_mod, sy
             got = scenes.run(g, sc, "integrate")
         scenes.compare_rows(ref, got)
         assert got.tobytes() == plain.tobytes(), form
+
+
+@pytest.mark.parametrize("host_batch,copy_streams", [("4", "2"), ("1", "2"), ("4", "1"), ("8", "4")])
+def test_host_frames_batched_over_several_copy_streams_equal_device_frames(hfpf_mod, synth_mod, monkeypatch, host_batch, copy_streams):
+    """The host-frame path under load: 24 frames of 640x480 handed to hfpf_integrate back to back, so that frames arrive while the
+    engine's stream is still busy and are launched in batches of up to HFPF_HOST_BATCH ring slots whose uploads alternate over
+    HFPF_COPY_STREAMS copy streams -- the kernels must wait for the last upload of EVERY stream that carried a slot of the batch
+    (round-3 advisor finding: only the last slot's event was waited for).  Same again from page-locked caller memory
+    (hfpf_integrate_pinned).  Rows and counters byte for byte those of the device-resident path."""
+    sc = scenes.Scene(24, 640, 480, 0.001, clean_every=12)
+    caps = dict(max_bricks=100000, max_log_points=16 << 20, max_normals=4 << 20, max_frames=256, frame_width=640)
+    keys = ("points_presented", "points_zclip_pass", "points_in_bbox", "points_buffered", "dep_pairs_tested", "dep_pairs_member",
+            "replay_members", "voxels_occupied", "voxels_with_normal", "registrations")
+    frames = [sc.frame(f) for f in range(sc.n_frames)]
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **caps) as b:
+        fb = sc.W * sc.H * 16
+        dev = b.device_alloc(12 * fb)
+        for half in range(2):
+            for j in range(12):
+                b.device_upload(dev + j * fb, frames[12 * half + j])
+            b.integrate_device(dev, 12, fb, sc.W * sc.H, np.stack(sc.poses[12 * half:12 * half + 12]))
+            b.clean()
+        ref = b.extract()
+        ref_ctr = b.counters()
+        b.device_free(dev)
+    assert len(ref) > 300000 and ref_ctr["dep_pairs_tested"] > 1e6
+    monkeypatch.setenv("HFPF_HOST_BATCH", host_batch)
+    monkeypatch.setenv("HFPF_COPY_STREAMS", copy_streams)
+    for pinned in (False, True):
+        with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **caps) as a:
+            bufs = frames
+            if pinned:
+                bufs = [a.host_alloc(sc.W * sc.H * 16) for _ in frames]
+                for hb, fr in zip(bufs, frames):
+                    hb[:] = np.frombuffer(fr, np.uint8)
+            for half in range(2):
+                for f in range(12 * half, 12 * half + 12):
+                    if pinned:
+                        a.integrate_pinned(bufs[f], sc.poses[f], n_points=sc.W * sc.H)
+                    else:
+                        a.integrate(bufs[f], sc.poses[f])
+                a.clean()
+            got = a.extract()
+            ctr = a.counters()
+            if pinned:
+                for hb in bufs:
+                    a.host_free(hb)
+        assert got.tobytes() == ref.tobytes(), "host frames (batch %s, %s copy streams, pinned=%s) differ from device frames" % (host_batch, copy_streams, pinned)
+        for k in keys:
+            assert ctr[k] == ref_ctr[k], k

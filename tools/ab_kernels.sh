@@ -7,6 +7,7 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for spec in "$@"; do
   name=${spec%%=*}; lib=${spec#*=}
+  case $lib in /*) ;; *) lib=$R/$lib ;; esac   # (the profiler runs from /tmp)
   rm -rf $R/gpurun_out/ab_$name
   HFPF_LIB=$lib timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ab_$name -o s -- python3 $R/bench.py --repeats 3 --warmup 0 --cpu-sample 0 --host-path-frames 0 $AB_ARGS > $R/gpurun_out/ab_$name.json 2> $R/gpurun_out/ab_$name.err || { echo "$name failed"; tail -3 $R/gpurun_out/ab_$name.err; continue; }
   python3 - "$name" "$R/gpurun_out/ab_$name" <<'PY'

@@ -18,6 +18,6 @@ if [ "$1" = "--rev" ]; then
 fi
 NAME=$1; shift
 mkdir -p $R/build/variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Wno-unused-result "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -Wno-unused-result "$@" \
   -shared -o $R/build/variants/$NAME.so $SRC/hfpf.hip
 echo "built build/variants/$NAME.so ($*)"
