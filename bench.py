@@ -55,7 +55,9 @@ BBOX = RES = None
 ALGO_BYTES_PER_POINT = 32  # 16 B point read + 16 B voxel-record touch
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBPS = 6290.0  # MI355X_MICROARCH.md: float4 copy
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_hot_path.json")
+# committed `rocprofv3 --pmc` summaries (tools/pmc_summary.py) per workload; attached only when taken on this build's kernel sources
+PMC_JSON = {"c1": os.path.join(ROOT, "profiles", "r04_pmc_hot_path.json"), "c3": os.path.join(ROOT, "profiles", "r04_c3_pmc_hot_path.json")}
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; one VALU wave-instruction holds a SIMD's issue for 4 cycles
 KERNEL_SOURCES = ("kernels.hpp", "tables.hpp", "stats.hpp", "geometry.hpp", "det_math.hpp", "hfpf.hip")
 
 
@@ -125,17 +127,20 @@ def claim_stdout():
     return real
 
 
-def load_pmc(src_sha):
+def load_pmc(src_sha, workload):
     """Measured HBM-side traffic of the integrate hot path from the committed `rocprofv3 --pmc` passes (PMC counters cannot
     be read inside this process).  Returns (dict or None, reason): refuses counters taken on different kernel sources."""
-    if not os.path.exists(PMC_JSON):
-        return None, "no %s (collect with tools/collect_profiles.sh + tools/pmc_summary.py)" % os.path.relpath(PMC_JSON, ROOT)
-    with open(PMC_JSON) as f:
+    path = PMC_JSON.get(workload)
+    if path is None:
+        return None, "no PMC passes are kept for workload %s" % workload
+    if not os.path.exists(path):
+        return None, "no %s (collect with tools/collect_profiles.sh / tools/collect_c3.sh + tools/pmc_summary.py)" % os.path.relpath(path, ROOT)
+    with open(path) as f:
         pmc = json.load(f)
     if pmc.get("source_sha") != src_sha:
         return None, "%s was collected on kernel sources %s, this build is %s: not measured for this build" % (
-            os.path.relpath(PMC_JSON, ROOT), pmc.get("source_sha"), src_sha)
-    return pmc, "%s (FETCH_SIZE with the gfx950 wide-read correction + WRITE_SIZE of the integrate kernels, separate --pmc passes on this build)" % os.path.relpath(PMC_JSON, ROOT)
+            os.path.relpath(path, ROOT), pmc.get("source_sha"), src_sha)
+    return pmc, "%s (FETCH_SIZE with the gfx950 wide-read correction + WRITE_SIZE of the integrate kernels, separate --pmc passes on this build)" % os.path.relpath(path, ROOT)
 
 
 def main():
@@ -343,7 +348,7 @@ def main():
         avg_launch_s = (k_ms / 1e3) / max(k_launches, 1)
         achieved = ALGO_BYTES_PER_POINT * pts_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         src_sha = kernel_source_sha()
-        pmc, traffic_src = load_pmc(src_sha)
+        pmc, traffic_src = load_pmc(src_sha, args.workload)
         traffic = atomic_req = None
         if pmc is not None:
             launches_per_pass = k_launches / R
@@ -400,6 +405,18 @@ def main():
                 compute = {"bound": "valu (k_update_cells)", "unit": "VALU lane-instructions per (point, dependant) pair", "achieved": round(li, 1),
                            "minimum": 48, "frac": round(48.0 / li, 4), "active_lane_fraction": round(lanes, 3),
                            "lds_bank_conflict_share": round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 4) if sq.get("SQ_LDS_IDX_ACTIVE") else None}
+        # ... and of k_integrate: the time its VALU wave-instructions alone need to issue (4 cycles each on one of 1024 SIMDs) against
+        # the kernel's measured time per steady call
+        compute_integrate = None
+        if pmc is not None and pmc.get("sq", {}).get("k_integrate", {}).get("SQ_INSTS_VALU") and per_kernel is not None and per_kernel["k_integrate"][1]:
+            sqi = pmc["sq"]["k_integrate"]
+            floor_ms = sqi["SQ_INSTS_VALU"] * 4.0 / (SIMDS * CLOCK_HZ) * 1e3
+            meas_ms = per_kernel["k_integrate"][0] / per_kernel["k_integrate"][1]
+            compute_integrate = {"bound": "valu issue (k_integrate)", "unit": "ms per steady integrate launch", "valu_issue_floor_ms": round(floor_ms, 4),
+                                 "measured_ms": round(meas_ms, 4), "frac": round(floor_ms / meas_ms, 4) if meas_ms > 0 else None,
+                                 "valu_wave_instructions": round(sqi["SQ_INSTS_VALU"]), "salu_wave_instructions": round(sqi.get("SQ_INSTS_SALU", 0)),
+                                 "active_lane_fraction": round(sqi["active_lane_fraction"], 3) if sqi.get("active_lane_fraction") else None,
+                                 "note": "measured_ms averages every k_integrate launch of a pass incl. the first epoch's; the counters are means over the steady launches"}
         if ctr["dep_pairs_tested"] == 0:
             warnings.append("dep_pairs_tested == 0: the stream never reached the steady state (no dependant updates ran); not the headline configuration")
         out = {
@@ -440,12 +457,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "the integrate call (bin plan + k_integrate + k_update_cells + k_buffer), HIP events on the engine's stream around every call of the timed passes",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBPS, 6),
+                         # the same 32 B/pt over the driver-timed quantity itself (ms_per_step: integrate calls AND clean passes)
+                         "whole_job_frac": round(ALGO_BYTES_PER_POINT * total_pts / world / elapsed / 1e9 / HBM_PEAK_GBPS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_source_sha": src_sha,
                          "algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT, "points_per_launch": round(pts_per_launch), "launches": int(k_launches),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5),
                          # secondary ceiling: memory-side atomic requests, chip-wide 1.3 TB/s / 64 B (MI355X_MICROARCH.md);
                          # request counts from the same PMC passes, null when those are not of this build
-                         "kernels": kernels, "compute": compute,
+                         "kernels": kernels, "compute": compute, "compute_integrate": compute_integrate,
                          "secondary": {"bound": "memory-side atomic requests", "unit": "Greq/s",
                                        "achieved": round(atomic_req / avg_launch_s / 1e9, 3) if atomic_req and avg_launch_s > 0 else None,
                                        "peak": round(1300.0 / 64.0, 3),

@@ -462,6 +462,7 @@ int check_device_errors(hfpf_handle* h)
     if (e & E_DEPCNT) what += " more than 65535 dependants on one cell";
     if (e & E_FRAME) what += " frame id >= max_frames";
     if (e & E_OVF) what += " integrate overflow list";
+    if (e & E_CHAIN) what += " point-log chain / run record out of range (internal)";
     return fail(h, HFPF_ERR_CAPACITY, "device pool overflow:%s", what.c_str());
 }
 
@@ -638,12 +639,11 @@ int alloc_tables(hfpf_handle* h)
         const char* ts = getenv("HFPF_TEST_TABLE_SKIP");
         t.test_table_skip = (ts && ts[0] == '1') ? 1u : 0u;
     }
-    ALLOC(nv_line, 2 * (t.max_normals + 1), 0, false);
     ALLOC(nd_mask, (t.max_bricks + 1) * 8 * 2, 0, false);
     ALLOC(reg_occ, t.max_reg, 0, false);
-    ALLOC(dep, t.max_dep, 0, false);
+    ALLOC(dep, t.max_dep + t.max_normals + 1, 0, false);  // dep[] and, behind it, the records' lines (one 32-byte entry each): one entry space
+    t.nv_line = reinterpret_cast<float4*>(t.dep + t.max_dep);
     ALLOC(prereg_list, t.max_reg, 0, false);
-    ALLOC(prechg_list, t.max_reg, 0, false);
     ALLOC(touched_list, h->max_touched, 0, false);
     ALLOC(run_start, t.max_bricks + 2, 0, false);
     ALLOC(run_len, t.max_bricks + 2, 0, false);
@@ -658,8 +658,16 @@ int alloc_tables(hfpf_handle* h)
     h->binned = (c.flags & HFPF_FLAG_DIRECT_UPDATE) == 0;
 #undef ALLOC
     t.log_region_cap = t.max_log / kLogRegions;
+    t.ent_base = t.dep;
+    t.ent_dep_first = 0;
+    t.ent_nv_first = t.max_dep;  // (max_dep < 2^32 and max_normals < 2^32: far inside the 40-bit entry index of k_update_cells)
     return reset_state(h);
 }
+
+// (rocPRIM sorts fewer than a million keys by block sort + log2(n / 1024) merge launches -- nine launches, 57 us, for the 74 K candidate
+// keys of a steady clean pass.  Forcing its radix path for small inputs, radix_sort_config<..., 8192>, was measured in round 4: a
+// histogram, a scan and per 8-bit digit two buffer fills and one sweep, fifteen launches and ~100 us for the same keys.  Default kept.)
+using sort_config = rocprim::default_config;
 
 // Cell keys: only the low GridParams::key_bits bits are significant (an all-ones sentinel still sorts behind every valid key:
 // a valid cell has x < dim <= 2^bits_x - 1, so its key is never all ones).
@@ -667,22 +675,22 @@ int sort_keys_u64(hfpf_handle* h, uint64_t* in, uint64_t* out, uint64_t n, unsig
 {
     const unsigned kb = bits ? bits : h->g.key_bits;
     size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys<sort_config>(nullptr, bytes, in, out, (size_t)n, 0, kb, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
     bytes = h->sort_tmp.bytes;
-    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, kb, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys<sort_config>(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, kb, h->stream));
     return HFPF_OK;
 }
 
 int sort_keys_u32(hfpf_handle* h, uint32_t* in, uint32_t* out, uint64_t n, unsigned bits = 32)
 {
     size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, bits, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys<sort_config>(nullptr, bytes, in, out, (size_t)n, 0, bits, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
     bytes = h->sort_tmp.bytes;
-    HIPCHK(h, rocprim::radix_sort_keys(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, bits, h->stream));
+    HIPCHK(h, rocprim::radix_sort_keys<sort_config>(h->sort_tmp.p, bytes, in, out, (size_t)n, 0, bits, h->stream));
     return HFPF_OK;
 }
 
@@ -690,11 +698,11 @@ int sort_pairs_u64(hfpf_handle* h, uint64_t* kin, uint64_t* kout, uint32_t* vin,
 {
     const unsigned kb = h->g.key_bits;
     size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, kb, h->stream));
+    HIPCHK(h, rocprim::radix_sort_pairs<sort_config>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, kb, h->stream));
     int rc = scratch(h, h->sort_tmp, bytes);
     if (rc) return rc;
     bytes = h->sort_tmp.bytes;
-    HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0, kb, h->stream));
+    HIPCHK(h, rocprim::radix_sort_pairs<sort_config>(h->sort_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0, kb, h->stream));
     return HFPF_OK;
 }
 
@@ -789,6 +797,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     }
     const bool color = h->t.color != 0;
     const bool bin = h->binned;
+    const uint32_t pre_possible = (h->h_ctr[C_NORMALS] > 0 || h->normals_possible) ? 1u : 0u;  // a clean pass has run: unoccupied cells may carry a dependant
     uint32_t launch_frames = n_frames, probe = 0;
     if (bin && !h->bin_have_hist && n_frames > (uint32_t)kProbeFrames) {
         // No plan for the per-brick bins yet (first batch of a session): a dry run of the batch's first frames claims their
@@ -803,7 +812,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
 #define HFPF_LAUNCH_PROBE(P, C)                                                                                                                    \
     hipLaunchKernelGGL((k_integrate<P, C, true>), pgrid, block, 0, h->stream,                                                                        \
                        IntegrateArgs{h->g, h->t}, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, lay, (const double*)s->d_pose, \
-                       (const uint32_t*)s->d_ids, row_w, log_rot, probe)
+                       (const uint32_t*)s->d_ids, row_w, log_rot, probe, pre_possible)
         if (packed && !color) HFPF_LAUNCH_PROBE(true, false);
         else if (packed && color) HFPF_LAUNCH_PROBE(true, true);
         else if (!color) HFPF_LAUNCH_PROBE(false, false);
@@ -909,7 +918,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
 #define HFPF_LAUNCH_INTEGRATE(P, C, B)                                                                                                              \
     hipLaunchKernelGGL((k_integrate<P, C, B>), grid, block, 0, h->stream,                                                                           \
                        IntegrateArgs{h->g, h->t}, (const uint8_t*)dev_base, frame_stride, n_points, launch_frames, lay, (const double*)s->d_pose, \
-                       (const uint32_t*)s->d_ids, row_w, log_rot, probe)
+                       (const uint32_t*)s->d_ids, row_w, log_rot, probe, pre_possible)
     if (!bin) {
         if (packed && !color) HFPF_LAUNCH_INTEGRATE(true, false, false);
         else if (packed && color) HFPF_LAUNCH_INTEGRATE(true, true, false);
@@ -1095,7 +1104,7 @@ int epoch_import_locked(hfpf_handle* h, const void* dev_records, uint64_t n)
 {
     if (n == 0) return HFPF_OK;
     h->pub_seq = 0;  // the import changes counters behind any snapshot already on its way
-    hipLaunchKernelGGL(k_epoch_import, dim3(blocks_for(n, 256 * kRegTiles)), dim3(256), 0, h->stream, h->g, h->t, (const EpochRec*)dev_records, n);
+    hipLaunchKernelGGL(k_epoch_import, dim3(blocks_for(n, 256 * kImportTiles)), dim3(256), 0, h->stream, h->g, h->t, (const EpochRec*)dev_records, n);
     HIPCHK(h, hipGetLastError());
     return HFPF_OK;
 }
@@ -1255,7 +1264,17 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     if (n_in == 0) return HFPF_OK;
     if ((rc = scratch(h, h->pend_b, n_in * 4))) return rc;
     if ((rc = scratch(h, h->keys_a, n_in * 8))) return rc;
-    hipLaunchKernelGGL(k_clean_begin, dim3(blocks_for(n_in, 256)), dim3(256), 0, s, t, n_in);  // sentinels + the pass's list counters
+    // The registration counts of this pass are bounded by (2K+1) * n_in; the kernels below read the exact counts from the
+    // device counters (kCountOnDevice), and the host picks the values up at the read-back after them.
+    const uint64_t reg_ub = (2ull * (uint64_t)h->g.K + 1ull) * n_in;
+    // Incremental update of the dependant table, or a compacting rebuild?  A conservative space estimate decides (C_DEP as of the
+    // read-back above: nothing has changed it since).  What one incremental update can take from dep[]: every relocated list (at
+    // most all live entries: registrations + filed pre-dependants so far), two entries per registration bound of this pass, and
+    // one entry per cell occupied since the last pass (the pre-dependants filed at the head of the pass).
+    const uint64_t live_ub = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg) + std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
+    bool full = h->h_ctr[C_DEP] + live_ub + 3 * reg_ub + n_new_occ > t.max_dep;
+    // sentinels + the pass's list counters + the pre-dependants of the cells occupied since the last pass become their lists
+    hipLaunchKernelGGL(k_clean_begin, dim3(blocks_for(n_in, 256)), dim3(256), 0, s, t, n_in, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, full ? 1u : 0u);
     launch_gate(h, (const uint32_t*)h->pend_a.p, n_pend, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, (uint32_t*)h->pend_b.p);
     HIPCHK(h, hipGetLastError());
     h->gate_done = n_occ;
@@ -1268,22 +1287,15 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     const unsigned cand_bits = HFPF_MORTON_IDS ? 3u * std::max(h->g.key_sy, std::max(h->g.key_sx - h->g.key_sy, h->g.key_bits - h->g.key_sx)) : h->g.key_bits;
     if ((rc = sort_keys_u64(h, t.cand_key, (uint64_t*)h->keys_a.p, n_in, cand_bits))) return rc;
     hipLaunchKernelGGL(k_normal, dim3(blocks_for(n_in, 128)), dim3(128), 0, s, h->g, t, (const uint64_t*)h->keys_a.p, kCountOnDevice, n_normals);
-    const uint64_t reg_tile = 256ull * kRegTiles;  // step-major, whole workgroups (kRegTiles tiles each) per step
+    const bool reg_small = n_in < (1ull << 18);  // tiles per workgroup: kernels.hpp k_register
+    const uint64_t reg_tile = 256ull * (reg_small ? kRegTilesSmall : kRegTilesLarge);  // step-major, whole workgroups per step
     const uint64_t reg_blocks = ((n_in + reg_tile - 1) / reg_tile) * (2ull * (uint64_t)h->g.K + 1ull);
-    hipLaunchKernelGGL(k_register, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals);
+    if (reg_small) hipLaunchKernelGGL(k_register<kRegTilesSmall>, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals);
+    else hipLaunchKernelGGL(k_register<kRegTilesLarge>, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals);
     HIPCHK(h, hipGetLastError());
-    // The registration counts of this pass are bounded by (2K+1) * n_in; the kernels below read the exact counts from the
-    // device counters (kCountOnDevice), and the host picks the values up at the read-back after them.
-    const uint64_t reg_ub = (2ull * (uint64_t)h->g.K + 1ull) * n_in;
     uint64_t n_reg = 0, n_pre = 0, inc_touched = 0;
     // registrations already present in dep[]: every pass files all of its own, so that is the counter as this pass found it
     const uint64_t reg_first = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg);
-    // incremental update; a conservative space estimate decides whether to compact instead (C_DEP as of the last readback:
-    // nothing has changed it since)
-    // What one incremental update can take from dep[]: every relocated list (at most all live entries: registrations + single
-    // entries so far) plus two entries per registration bound of this pass.
-    const uint64_t live_ub = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg) + std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
-    bool full = h->h_ctr[C_DEP] + live_ub + 3 * reg_ub > t.max_dep;
     // A pass is SMALL when its upper bounds are: then the replay is launched over the bound and reads the touched-cell count on
     // the device, and the host does not wait for the pass at all (no mid-pass read-back: the GPU is not left idle for a host
     // round trip, and the next integrate call is enqueued behind the replay at once).  The bound above makes sure the pass
@@ -1291,7 +1303,7 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     const bool no_wait = !full && reg_ub < (1ull << 21) && h->clean_small_nowait;
     if (!full) {
         const unsigned count_blocks = blocks_for(reg_ub, 256 * kListTiles);
-        hipLaunchKernelGGL(k_depinc_count_pre, dim3(2 * count_blocks), dim3(256), 0, s, t, reg_first, kCountOnDevice, kCountOnDevice, count_blocks);
+        hipLaunchKernelGGL(k_depinc_count, dim3(count_blocks), dim3(256), 0, s, t, reg_first, kCountOnDevice);
         hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, kCountOnDevice);
         hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(reg_ub, 256)), dim3(256), 0, s, t, reg_first, kCountOnDevice);
         HIPCHK(h, hipGetLastError());
@@ -1620,7 +1632,8 @@ static int flush_pending_locked(hfpf_handle* h)
     }
     int rc = integrate_device_locked(h, (const char*)h->ring_d + (size_t)first * h->ring_cap, n, h->ring_cap, h->pend_pts, h->pend_lay[0], h->pend_lay[1],
                                      h->pend_lay[2], h->pend_lay[3], h->pend_lay[4], h->pend_pose, nullptr);
-    if (rc) return rc;
+    // frames that were accepted with HFPF_OK are lost: whichever entry point found them waiting, the handle stops until hfpf_clear
+    if (rc) return poison_on_error(h, rc);
     for (uint32_t k = 0; k < n; k++) {
         FrameSlot& f = h->fslot[first + k];
         HIPCHK(h, hipEventRecord(f.done, h->stream));

@@ -52,7 +52,8 @@ constexpr uint32_t kLogUnlinked = 0x80000000u;  // log entry .w = slot | this bi
 #ifndef HFPF_REG_TILES
 #define HFPF_REG_TILES 8  // 256-voxel tiles one workgroup of k_register takes per list reservation
 #endif
-constexpr int kRegTiles = HFPF_REG_TILES;
+constexpr int kRegTilesLarge = HFPF_REG_TILES, kRegTilesSmall = 2;
+constexpr int kImportTiles = HFPF_REG_TILES;  // k_epoch_import: tiles per workgroup (one occ_list reservation)
 // Passed instead of an element count: the kernel reads the exact count from its device counter and the host sizes the grid
 // from an upper bound, which saves a host round trip between two kernels of a clean pass.
 constexpr uint64_t kCountOnDevice = ~0ull;
@@ -150,6 +151,31 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 #endif
 }
 
+__device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid)  // (nv_line holds every record's line in the layout of a dependant entry)
+{
+    return *reinterpret_cast<const DepEntry*>(&t.nv_line[2 * (uint64_t)nid]);
+}
+// A cell gained its first dependant: set its bit in the brick's flag line (read by k_integrate).
+__device__ __forceinline__ void set_dep_flag(const Tables& t, uint32_t slot)
+{
+    uint64_t plane, bit;
+    slot_plane_bit(slot, plane, bit);
+    atomicOr(reinterpret_cast<unsigned long long*>(&t.nd_mask[plane * 2 + 1]), (unsigned long long)bit);
+}
+// The ONE dependant a cell can carry while it is unoccupied (grid.hpp:443-449: the last registrant wins) lives in pre_dep[slot]
+// alone -- no list entry, no flag bit, nothing a clean pass has to write per unoccupied target but the atomicMax that settles the
+// winner (most registration targets are unoccupied: 8 M of the 13.7 M in the bench's first pass, and on 0.5 mm voxels the slot
+// arrays they used to touch fall out of the caches).  A cell that has become occupied gets the entry filed as its dependant list
+// at the head of the next clean pass (k_materialize_new: list entry, info word, flag bit, a place in prereg_list for compacting
+// rebuilds).  In between -- the cell was occupied in the running epoch -- whoever reads dependant lists while points arrive
+// (k_update_cells, k_update, k_integrate_overflow, the un-binned k_integrate) takes an EMPTY list of an occupied cell to mean
+// "look at pre_dep": the one entry is the record's own line, which nv_line keeps in the layout of a dependant entry.
+__device__ __forceinline__ void pre_list_entry(const Tables& t, uint32_t nid, float4& e0, float4& e1)  // = the two halves of make_dep_entry(t, nid)
+{
+    e0 = t.nv_line[2 * (uint64_t)nid];
+    e1 = t.nv_line[2 * (uint64_t)nid + 1];
+}
+
 // The direct forms of buffering (grid.hpp:205-243) and of the dependant update (grid.hpp:244-277) for one point per lane: the whole
 // path of the un-binned engine (BIN = false, inline in k_integrate), and in the binned one what k_integrate_overflow does with the
 // few points that found no room in their brick's bin.  Convergent for the wave (every lane calls; `todo` says which have a point).
@@ -186,18 +212,23 @@ __device__ __forceinline__ void direct_buffer(const Tables& t, unsigned long lon
 template <bool COLOR, bool BIN>
 __device__ __forceinline__ void direct_forms(const GridParams& g, const Tables& t, unsigned long long* q, unsigned long long* log_ctr, const uint64_t log_base,
                                              const F3 p, const uint32_t slot, const uint32_t b, const uint32_t fid, const uint32_t rgb, const bool todo,
-                                             const bool has_n, const bool has_d, uint32_t& c_buf, uint32_t& c_tested, uint32_t& c_member)
+                                             const bool has_n, const bool has_d, const uint32_t pre_nid, uint32_t& c_buf, uint32_t& c_tested, uint32_t& c_member)
 {
     direct_buffer<COLOR, BIN>(t, log_ctr, log_base, p, slot, b, fid, rgb, todo, has_n, c_buf);
 
-    // direct dependant updates
+    // direct dependant updates.  pre_nid != 0: the cell was occupied in the running epoch and has no list yet, only the dependant it
+    // was given while unoccupied (pre_list_entry): the point is tested against that record's own line.
     const bool direct = todo && has_d;
     uint32_t cnt = 0;
     uint64_t off = 0;
     if (direct) {
-        const uint64_t info = t.info[slot];
-        cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-        off = info >> kDepOffShift;
+        if (pre_nid) {
+            cnt = 1;
+        } else {
+            const uint64_t info = t.info[slot];
+            cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
+            off = info >> kDepOffShift;
+        }
     }
     uint32_t max_cnt = cnt;
 #pragma unroll
@@ -208,7 +239,7 @@ __device__ __forceinline__ void direct_forms(const GridParams& g, const Tables& 
         stat_delta_zero(d);
         uint32_t sid = 0;
         if (j < cnt) {
-            const DepEntry e = t.dep[off + j];
+            const DepEntry e = pre_nid ? make_dep_entry(t, pre_nid) : t.dep[off + j];
             float sp, distf;
             c_tested++;
             if (line_member(g, p, F3{e.ax, e.ay, e.az}, F3{e.abx, e.aby, e.abz}, e.dd, sp, distf)) {
@@ -253,13 +284,17 @@ __device__ __forceinline__ const Tables& kernarg_tables()
 #ifndef HFPF_INT_WAVES_BIN
 #define HFPF_INT_WAVES_BIN 7
 #endif
+#ifndef HFPF_INT_REGION_LOADS_BY_ALL
+#define HFPF_INT_REGION_LOADS_BY_ALL 0
+#endif
 template <bool PACKED16, bool COLOR, bool BIN>
 __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) void k_integrate(const IntegrateArgs A, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
                                                    const FrameLayout lay, const double* __restrict__ poses,
                                                    const uint32_t* __restrict__ frame_ids, const uint32_t row_w, const uint32_t log_rot,
-                                                   const uint32_t probe)
+                                                   const uint32_t probe, const uint32_t pre_possible)
 {
+    // pre_possible: a clean pass has run, so unoccupied cells may carry a dependant (k_materialize_new)
     const GridParams& g = A.g;
     const Tables& t = A.t;
     // probe != 0: dry run of the batch's first frames for a session that has no bin plan yet -- transform, index, claim the
@@ -396,6 +431,14 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
             const unsigned long long old = atomicOr(om, (unsigned long long)bit);
             first = !(old & bit);  // (occupancy lives in occ_mask alone; the cell's info word is not touched)
         }
+        // A cell occupied since the last clean pass has no list and no flag yet, but it may carry the ONE dependant it was given
+        // while unoccupied (pre_dep, see k_materialize_new): every reader of the lists falls back on it.  The binned form parks
+        // every point of a cell without a normal anyway and its per-brick kernels do the looking; the direct form looks here.
+        uint32_t pre_nid = 0;
+        if (!BIN && pre_possible && act && !has_n && !has_d && !probe) {
+            pre_nid = t.pre_dep[slot];
+            has_d = pre_nid != 0;
+        }
         // newly occupied cells are staged in LDS (per wave) and appended to occ_list in batches: C_OCC is one address for the
         // whole chip (a same-address atomic retires every ~12 ns), so it gets one atomic per flush, not one per tile.  The
         // count lives in a wave-uniform register, so no two waves ever have to agree on a flush (no barrier in the tile loop).
@@ -431,14 +474,22 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
             // phase 2: every group leader reserves for its group in ONE wave-instruction (one memory round trip per tile);
             // the counter also records the demand the next launch's plan is made from
             uint32_t base = 0, cap = 0, roff = 0;
+            if (want_bin && grp_leader == lane) base = atomicAdd(&t.bin_fill[rg], grp_size);
+#if HFPF_INT_REGION_LOADS_BY_ALL
+            if (want_bin) {  // the region's capacity and first entry, read by every lane of the group (one address: one request) instead of
+                cap = t.bin_capb[rg];  // by its leader and handed round through two more cross-lane reads
+                roff = t.bin_off[rg];
+            }
+            base = __shfl(base, (int)grp_leader);
+#else
             if (want_bin && grp_leader == lane) {
-                base = atomicAdd(&t.bin_fill[rg], grp_size);
                 cap = t.bin_capb[rg];
                 roff = t.bin_off[rg];
             }
             base = __shfl(base, (int)grp_leader);
             cap = __shfl(cap, (int)grp_leader);
             roff = __shfl(roff, (int)grp_leader);
+#endif
             if (todo && !probe) {
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
@@ -467,7 +518,7 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
                 }
             }
         } else {
-            direct_forms<COLOR, false>(g, t, q, log_ctr, log_base, p, slot, b, fid, rgb, todo, has_n, has_d, c_buf, c_tested, c_member);
+            direct_forms<COLOR, false>(g, t, q, log_ctr, log_base, p, slot, b, fid, rgb, todo, has_n, has_d, pre_nid, c_buf, c_tested, c_member);
         }
     }
     if (occ_n) flush_occ_stage(t, s_occ, occ_n);  // wave-uniform
@@ -504,7 +555,8 @@ __global__ __launch_bounds__(256) void k_integrate_overflow(const GridParams g, 
     __shared__ unsigned int blk_ctr[3];
     __shared__ float s_x[256], s_y[256], s_z[256];
     __shared__ uint32_t s_rgb[COLOR ? 256 : 1];
-    __shared__ uint32_t s_off[256];    // first dependant entry of the point's cell (dep[] stays below 2^32 entries, host-checked)
+    __shared__ uint32_t s_off[256];    // first dependant entry of the point's cell (dep[] stays below 2^32 entries, host-checked), or ...
+    __shared__ uint8_t s_pre[256];     // ... 1: the record id of the cell's pre-dependant (cell occupied in this epoch: pre_list_entry)
     __shared__ uint32_t s_pref[257];   // pairs in front of the point
     __shared__ uint32_t s_wsum[4];
     const uint64_t n = min((uint64_t)t.ctr[C_OVF], t.ovf_cap);  // the same in every thread of the grid (nothing appends while this kernel runs)
@@ -528,10 +580,16 @@ __global__ __launch_bounds__(256) void k_integrate_overflow(const GridParams g, 
         }
         const uint32_t slot = __float_as_uint(rec.w);
         uint32_t cnt = 0, off = 0;
-        if (todo && (aux.x & kOvfHasDeps)) {  // issued before the buffering's atomics
+        bool pre = false;
+        if (todo && ((aux.x & kOvfHasDeps) || !(aux.x & kOvfHasNormal))) {  // issued before the buffering's atomics
             const uint64_t info = t.info[slot];
             cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
             off = (uint32_t)(info >> kDepOffShift);
+            if (cnt == 0 && !(aux.x & kOvfHasNormal)) {  // no list yet: a cell occupied in this epoch may carry a pre-dependant
+                off = t.pre_dep[slot];
+                pre = off != 0;
+                cnt = pre ? 1u : 0u;
+            }
         }
         direct_buffer<COLOR, true>(t, log_ctr, log_base, F3{rec.x, rec.y, rec.z}, slot, slot >> 9, aux.x & ~(kOvfHasNormal | kOvfHasDeps), aux.y, todo,
                                    (aux.x & kOvfHasNormal) != 0, c_buf);
@@ -540,11 +598,12 @@ __global__ __launch_bounds__(256) void k_integrate_overflow(const GridParams g, 
         s_x[tid] = rec.x, s_y[tid] = rec.y, s_z[tid] = rec.z;
         if (COLOR) s_rgb[tid] = aux.y;
         s_off[tid] = off;
+        s_pre[tid] = pre ? 1 : 0;
         __syncthreads();
-        uint32_t pre = inc - cnt;
-        for (uint32_t w2 = 0; w2 < wave; w2++) pre += s_wsum[w2];
-        s_pref[tid] = pre;
-        if (tid == 255) s_pref[256] = pre + cnt;
+        uint32_t before = inc - cnt;
+        for (uint32_t w2 = 0; w2 < wave; w2++) before += s_wsum[w2];
+        s_pref[tid] = before;
+        if (tid == 255) s_pref[256] = before + cnt;
         __syncthreads();
         const uint32_t total = s_pref[256];
         for (uint32_t k0 = 0; k0 < total; k0 += 256u) {  // block-uniform trip count
@@ -561,7 +620,7 @@ __global__ __launch_bounds__(256) void k_integrate_overflow(const GridParams g, 
                     if (s_pref[mid] <= k) lo = mid;
                     else hi = mid;
                 }
-                const DepEntry e = t.dep[(uint64_t)s_off[lo] + (k - s_pref[lo])];
+                const DepEntry e = s_pre[lo] ? make_dep_entry(t, s_off[lo]) : t.dep[(uint64_t)s_off[lo] + (k - s_pref[lo])];
                 float sp, distf;
                 c_tested++;
                 if (line_member(g, F3{s_x[lo], s_y[lo], s_z[lo]}, F3{e.ax, e.ay, e.az}, F3{e.abx, e.aby, e.abz}, e.dd, sp, distf)) {
@@ -603,6 +662,7 @@ __global__ __launch_bounds__(256) void k_integrate_overflow(const GridParams g, 
 #define HFPF_UPD_BITS 9  // log2 of the LDS table size of k_update
 #endif
 constexpr int kUpdSlots = 1 << HFPF_UPD_BITS;
+constexpr unsigned long long kPreListBit = 1ull << 63;  // in a staged info word: the list is the cell's pre-dependant alone (pre_list_entry)
 constexpr int kUpdThreads = 256;
 #ifndef HFPF_UPD_LANES
 #define HFPF_UPD_LANES 2  // lanes that share one point in k_update (1, 2, 4 or 8)
@@ -630,10 +690,19 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
     float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid / kUpdLanes < fill) pe = t.bin_pt[entry(tid / kUpdLanes)];  // in flight while the tables are set up
     {
-        const ulonglong2 inf = *reinterpret_cast<const ulonglong2*>(&t.info[(uint64_t)b * kBrickCells + 2u * tid]);
+        ulonglong2 inf = *reinterpret_cast<const ulonglong2*>(&t.info[(uint64_t)b * kBrickCells + 2u * tid]);
         for (uint32_t i = tid; i < (uint32_t)kUpdSlots; i += 256) keys[i] = 0;
         for (uint32_t i = tid; i < (uint32_t)(kUpdSlots * W); i += 256) vals[i] = 0;
         if (tid < 2) blk_ctr[tid] = 0;
+        // an empty list may belong to a cell occupied in this epoch that carries a pre-dependant: a list of one, marked by bit 63,
+        // whose "offset" is the record id (pre_list_entry)
+        auto with_pre = [&](unsigned long long info, uint32_t cell) -> unsigned long long {
+            if ((info >> kDepCntShift) & kDepCntMask) return info;
+            const uint32_t pd = t.pre_dep[(uint64_t)b * kBrickCells + cell];
+            return pd ? ((info & 3ull) | (1ull << kDepCntShift) | ((unsigned long long)pd << kDepOffShift) | kPreListBit) : info;
+        };
+        inf.x = with_pre(inf.x, 2u * tid);
+        inf.y = with_pre(inf.y, 2u * tid + 1u);
         s_info[2u * tid] = inf.x;
         s_info[2u * tid + 1] = inf.y;
     }
@@ -651,12 +720,16 @@ __global__ __launch_bounds__(256) void k_update(const GridParams g, const Tables
         const F3 p = F3{cur.x, cur.y, cur.z};
         const uint64_t info = s_info[__float_as_uint(cur.w) & (kBrickCells - 1)];
         const uint32_t cnt = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
-        const uint64_t off = info >> kDepOffShift;
+        const uint64_t off = (info & ~kPreListBit) >> kDepOffShift;
         if (sub == 0) c_tested += cnt;
         float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
         if (sub < cnt) {
-            n0 = dep4[2 * (off + sub)];
-            n1 = dep4[2 * (off + sub) + 1];
+            if (info & kPreListBit) {
+                pre_list_entry(t, (uint32_t)off, n0, n1);
+            } else {
+                n0 = dep4[2 * (off + sub)];
+                n1 = dep4[2 * (off + sub) + 1];
+            }
         }
         for (uint32_t j = sub; j < cnt; j += kUpdLanes) {
             const float4 e0 = n0, e1 = n1;
@@ -796,7 +869,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
     __shared__ float s_px[kUpd2Cap], s_py[kUpd2Cap], s_pz[kUpd2Cap];  // sorted points, one array per coordinate (12 bytes a point)
     __shared__ uint32_t s_rgb[COLOR ? kUpd2Cap : 1];
     __shared__ uint32_t s_cnt[kBrickCells];
-    __shared__ uint64_t s_pack[kBrickCells];       // per cell and round: dependant-list offset (32) | first sorted position (12) | points (12)
+    // per cell and round: first entry of the dependant list (40 bits: an index into ONE entry space that holds dep[] and, for a cell whose
+    // "list" is its pre-dependant, the records' own lines -- Tables::ent_base) | first sorted position (12) | points (12)
+    __shared__ uint64_t s_pack[kBrickCells];
     __shared__ uint32_t s_items[kBrickCells + 1];  // first work item of each cell (only the search path and the total read it)
     __shared__ uint32_t s_desc[kUpd2Desc];         // per work item: cell (9) | chunk (8) | entry (15)
     __shared__ uint32_t s_wsum[2][T / 64];
@@ -812,16 +887,23 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
     if (fill == 0) return;  // block-uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t first_a = REPLAY ? t.run_start[b] : t.bin_off[2 * b], first_b = REPLAY ? 0u : t.bin_off[2 * b + 1];
+    if (REPLAY && first_a + fill_a > t.max_log + 1) {  // block-uniform; a run record that leaves the log (cannot happen: k_buffer records a run only when it fits)
+        if (threadIdx.x == 0) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_CHAIN);
+        return;
+    }
     auto entry = [&](uint32_t i) -> uint64_t { return i < fill_a ? first_a + i : first_b + (i - fill_a); };
     const bool scanner = tid < (uint32_t)kBrickCells / CPT;  // wave-uniform: the threads that own cells
-    uint32_t own_cnt[CPT], own_off[CPT];
+    uint32_t own_cnt[CPT], own_off[CPT], own_pre = 0;
     bool any_note = false;
 #pragma unroll
     for (uint32_t k = 0; k < CPT; k++) {
         const uint64_t cslot = (uint64_t)b * kBrickCells + tid * CPT + k;
         const uint64_t info = scanner ? t.info[cslot] : 0ull;
+        const uint32_t pd = (!REPLAY && scanner) ? t.pre_dep[cslot] : 0u;  // (read beside the info word, not behind it: one round trip)
         own_cnt[k] = (uint32_t)((info >> kDepCntShift) & kDepCntMask);
         own_off[k] = (uint32_t)(info >> kDepOffShift);  // dep[] stays below 2^32 entries (host-checked)
+        // no list: a cell occupied in this epoch may carry a pre-dependant (a list of one: pre_list_entry)
+        if (!REPLAY && own_cnt[k] == 0 && pd) own_cnt[k] = 1, own_off[k] = pd, own_pre |= 1u << k;
         if (REPLAY) {  // only the registrants of the running pass: the entries behind the old list length
             const uint32_t note = scanner ? t.dep_tmp[cslot] : 0u;
             const bool noted = (note & kTouchedMark) != 0;
@@ -837,7 +919,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
     for (uint32_t i = tid; i < (uint32_t)kUpd2Slots; i += T) keys[i] = 0;
     for (uint32_t i = tid; i < (uint32_t)(kUpd2Slots * W); i += T) vals[i] = 0;
     if (tid < 3) blk_ctr[tid] = 0;
-    const float4* __restrict__ dep4 = reinterpret_cast<const float4*>(t.dep);
+    const float4* __restrict__ ent4 = reinterpret_cast<const float4*>(t.ent_base);  // dep[] and nv_line as one array of 32-byte entries
     uint32_t c_tested = 0, c_member = 0, c_miss = 0;
     // Software pipeline: the points of round r+1 are read from the bin while round r's items are worked (without it the streaming
     // replay, whose bricks take several rounds, is a third slower), and an item's dependant entry is read one item ahead (the first
@@ -886,16 +968,16 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
             }
             c = lo;
             const uint32_t local = item - s_items[lo];
-            const uint32_t chunks = ((uint32_t)((s_pack[lo] >> 44) & 0xFFFu) + CH - 1) / CH;
+            const uint32_t chunks = ((uint32_t)((s_pack[lo] >> 52) & 0xFFFu) + CH - 1) / CH;
             j = local / chunks;
             ch = local - j * chunks;
         }
         const uint64_t pk = s_pack[c];
-        const uint32_t n_c = (uint32_t)((pk >> 44) & 0xFFFu);
-        it.first = (uint32_t)((pk >> 32) & 0xFFFu);
-        const uint64_t e = (uint64_t)(uint32_t)pk + j;
-        it.e0 = dep4[2 * e];
-        it.e1 = dep4[2 * e + 1];
+        const uint32_t n_c = (uint32_t)((pk >> 52) & 0xFFFu);
+        it.first = (uint32_t)((pk >> 40) & 0xFFFu);
+        const uint64_t e = (pk & ((1ull << 40) - 1ull)) + j;
+        it.e0 = ent4[2 * e];
+        it.e1 = ent4[2 * e + 1];
         it.p_lo = ch * CH;
         it.p_hi = min(n_c, it.p_lo + CH);
     };
@@ -936,7 +1018,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
 #pragma unroll
             for (uint32_t k = 0; k < CPT; k++) {
                 const uint32_t c = tid * CPT + k;
-                s_pack[c] = (uint64_t)own_off[k] | ((uint64_t)pre_n << 32) | ((uint64_t)n[k] << 44);
+                s_pack[c] = ((((own_pre >> k) & 1u) ? t.ent_nv_first : t.ent_dep_first) + own_off[k]) | ((uint64_t)pre_n << 40) | ((uint64_t)n[k] << 52);
                 s_items[c] = pre_it;
                 if (it[k]) {
                     const uint32_t chunks = (n[k] + CH - 1) / CH;
@@ -960,7 +1042,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++)
             if (tid + k * T < n_round) {
-                const uint32_t pos = (uint32_t)((s_pack[__float_as_uint(pt[k].w) & (kBrickCells - 1)] >> 32) & 0xFFFu) + rk[k];
+                const uint32_t pos = (uint32_t)((s_pack[__float_as_uint(pt[k].w) & (kBrickCells - 1)] >> 40) & 0xFFFu) + rk[k];
                 s_px[pos] = pt[k].x;
                 s_py[pos] = pt[k].y;
                 s_pz[pos] = pt[k].z;
@@ -999,6 +1081,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
             c_tested += cur.p_hi - cur.p_lo;
             c_member += (uint32_t)a_n;
             if (a_n == 0) continue;
+#ifdef HFPF_TIMING_ONLY_SKIP_DUP_INSERT  // timing-only build (results wrong on purpose): only the first chunk of a (cell, entry) touches the record table --
+            if (cur.p_lo != 0) continue;  // the most a reduction over the lanes of one record could save, before it costs anything itself
+#endif
             const uint32_t sid = __float_as_uint(cur.e0.x);
             uint32_t h = upd2_hash(sid);
             bool placed = false;
@@ -1361,18 +1446,42 @@ __device__ __forceinline__ uint64_t cand_count(const Tables& t, uint64_t base)
     return n < room ? n : room;
 }
 // Head of a clean pass, one launch: all-ones sentinels behind the candidate keys the gate is about to write (they sort to the
-// end) and the pass's list counters back to zero.
-__global__ __launch_bounds__(256) void k_clean_begin(const Tables t, const uint64_t n_in)
+// end), the pass's list counters back to zero, and (k_materialize_new in the comments: this part) the cells occupied since the
+// previous pass -- the new tail of occ_list, imported ones included -- that carry a pre-dependant get it filed as their list: entry,
+// info word, flag bit, and a place in prereg_list (what a compacting rebuild re-creates the entry from); one reservation per list
+// and workgroup.  lists_only: a compacting rebuild follows in this pass and writes every entry and info word itself.  No room in
+// dep[] is E_DEP, which the host answers by compacting.  n_in >= n_new (the gate's input contains the new cells).
+__global__ __launch_bounds__(256) void k_clean_begin(const Tables t, const uint64_t n_in, const uint32_t* __restrict__ new_cells, const uint64_t n_new,
+                                                     const uint32_t lists_only)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_in) t.cand_key[i] = ~0ull;
     if (i == 0) {
         t.ctr[C_CAND] = 0;
         t.ctr[C_PEND] = 0;
-        t.ctr[C_PRECHG] = 0;
         t.ctr[C_TOUCHED] = 0;
     }
     if (i < (uint64_t)kLogRegions) t.log_ctr[i * 16 + 4] = 0;  // touched cells in single-run bricks (k_depinc_offsets)
+    if ((uint64_t)blockIdx.x * blockDim.x >= n_new) return;  // block-uniform
+    uint32_t slot = 0, nid = 0;
+    if (i < n_new) {
+        slot = new_cells[i];
+        nid = t.pre_dep[slot];
+    }
+    __shared__ BlockReserveScratch brs;
+    const unsigned long long li = block_reserve(&t.ctr[C_PREREG], nid != 0, brs);
+    const unsigned long long off = lists_only ? 0ull : block_reserve(&t.ctr[C_DEP], nid != 0, brs);
+    if (!nid) return;
+    if (li < t.max_reg) t.prereg_list[li] = slot;
+    else atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
+    set_dep_flag(t, slot);
+    if (lists_only) return;
+    if (off >= t.max_dep) {
+        atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEP);
+        return;
+    }
+    t.dep[off] = make_dep_entry(t, nid);
+    t.info[slot] = (t.info[slot] & 3ull) | (1ull << kDepCntShift) | ((uint64_t)off << kDepOffShift);
 }
 
 // K4: one thread per candidate, in ascending order of the sorted keys (Z-order codes with HFPF_MORTON_IDS); record id = base + rank + 1.
@@ -1443,8 +1552,8 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
         F3 a, ab;
         float dd;
         line_of(g, centre, normal, a, ab, dd);
-        t.nv_line[2 * nid] = make_float4(a.x, a.y, a.z, ab.x);
-        t.nv_line[2 * nid + 1] = make_float4(ab.y, ab.z, dd, 0.f);
+        t.nv_line[2 * nid] = make_float4(__uint_as_float((uint32_t)nid), a.x, a.y, a.z);  // = DepEntry{sid, a, ab, |ab|^2}
+        t.nv_line[2 * nid + 1] = make_float4(ab.x, ab.y, ab.z, dd);
     }
     t.stat_id[slot] = (uint32_t)nid;
     atomicOr(reinterpret_cast<unsigned int*>(&t.info[slot]), 2u);  // normal_found, grid.hpp:398
@@ -1455,13 +1564,16 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
 // K5: one thread per (new normal, line step).  Occupancy is frozen during a clean pass, so the steps are
 // independent; "last registrant wins" on unoccupied cells (grid.hpp:443-449) is an atomicMax over record ids -- they ascend from
 // pass to pass -- with the contests inside a pass settled by the canonical (x, y, z) key (see below: ids follow the Z-order there).
+template <int kRegTiles>
 __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand_arg, const uint64_t base)
 {
     const uint64_t n_cand = n_cand_arg == kCountOnDevice ? cand_count(t, base) : n_cand_arg;  // the same in every thread
     if (n_cand == 0) return;
     // Step-major mapping: a wave holds 64 key-adjacent voxels at the SAME step, so its targets sit in the same few bricks.
-    // A workgroup takes kRegTiles consecutive 256-voxel tiles of one step and reserves its list entries once per list: the
-    // three list counters share a line, and same-line device atomics retire one per ~12 ns whoever issues them.
+    // A workgroup takes kRegTiles consecutive 256-voxel tiles of one step and reserves its list entries once: same-address device
+    // atomics retire one per ~12 ns whoever issues them.  The host takes 8 tiles for passes of millions of candidates (6.7 K
+    // reservations in the bench's first pass; 27 K would be a third of a millisecond) and 2 for the small steady ones, where the
+    // ~20 K candidates of a pass would otherwise sit on 70 of the 256 CUs.
     const uint32_t steps = 2u * (uint32_t)g.K + 1u;
     const uint64_t tile_items = 256ull * kRegTiles;
     const uint64_t per_step = ((n_cand + tile_items - 1) / tile_items) * tile_items;  // whole workgroups per step keep them uniform in i
@@ -1469,18 +1581,15 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
     const uint32_t step_idx = (uint32_t)(blk_first / per_step);
     const int i = (int)step_idx - g.K;
     uint32_t slot_[kRegTiles], nid_[kRegTiles];
-    uint64_t my_key_[kRegTiles];
-    uint32_t f_occ = 0, f_new = 0, f_chg = 0;
+    uint32_t f_occ = 0;
 #pragma unroll
     for (int tt = 0; tt < kRegTiles; tt++) {
         const uint64_t r = blk_first % per_step + (uint64_t)tt * 256u + threadIdx.x;
         bool want = r < n_cand && step_idx < steps;
         uint64_t nid = 0;
         int32_t xx = 0, yy = 0, zz = 0;
-        my_key_[tt] = 0;
         if (want) {
             nid = base + r + 1;
-            my_key_[tt] = t.nv_key[nid];  // (coalesced, with the record's other fields: a contest further down then costs one dependent read)
             const F3 c = F3{t.nv_c[3 * nid], t.nv_c[3 * nid + 1], t.nv_c[3 * nid + 2]};
             const F3 n = F3{t.nv_n[3 * nid], t.nv_n[3 * nid + 1], t.nv_n[3 * nid + 2]};
             const F3 nb = line_step(g, c, n, i);  // grid.hpp:405
@@ -1499,17 +1608,20 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         nid_[tt] = (uint32_t)nid;
         if (occ) f_occ |= 1u << tt;
         if (want && !occ) {
+            // An unoccupied target keeps ONE dependant, in pre_dep[slot] and nowhere else until the cell is occupied (k_materialize_new).
             const uint32_t old = atomicMax(&t.pre_dep[slot], (uint32_t)nid);
-            if (old == 0u) f_new |= 1u << tt;    // first registration ever on this cell
-            if (old <= base) f_chg |= 1u << tt;  // first change in THIS pass (ids of this pass are > base): exactly one lane sees it
+#ifdef HFPF_TEST_NO_KEY_CONTEST  // (tests only: shows that test_registration_contest_... notices a contest left to the ids)
+            if (false) {
+#else
             if (HFPF_MORTON_IDS && old > base && old != (uint32_t)nid) {
+#endif
                 // Another voxel of this pass registered here as well.  Ids follow the Z-order inside a pass, the contest is about the
                 // canonical order: the registrant with the LARGEST (x, y, z) KEY stays (the reference walks its candidates in that
                 // order and the last one overwrites, grid.hpp:443-449).  The atomicMax above has put the larger ID into the cell and
                 // told this lane whom it met; the lane now sees to it that the cell holds a key at least as large as the better of the
                 // two.  Whoever displaces a holder learns of it the same way and takes over that duty, so once every registrant is
                 // through, the cell holds the largest key of the pass.  (Uncontested cells -- most -- cost the one atomic they always did.)
-                const uint64_t my_key = my_key_[tt], old_key = t.nv_key[old];
+                const uint64_t my_key = t.nv_key[nid], old_key = t.nv_key[old];
                 const uint32_t best = old_key > my_key ? old : (uint32_t)nid;
                 const uint64_t best_key = old_key > my_key ? old_key : my_key;
                 uint32_t cur = max(old, (uint32_t)nid);  // what the atomicMax left behind
@@ -1523,30 +1635,16 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         }
     }
     __shared__ TileReserveScratch<kRegTiles> trs;
-    uint32_t n_occ[kRegTiles], n_new[kRegTiles], n_chg[kRegTiles];
-    unsigned long long ri[kRegTiles], pi[kRegTiles], ci[kRegTiles];
+    uint32_t n_occ[kRegTiles];
+    unsigned long long ri[kRegTiles];
 #pragma unroll
-    for (int tt = 0; tt < kRegTiles; tt++) {
-        n_occ[tt] = (f_occ >> tt) & 1u;
-        n_new[tt] = (f_new >> tt) & 1u;
-        n_chg[tt] = (f_chg >> tt) & 1u;
-    }
+    for (int tt = 0; tt < kRegTiles; tt++) n_occ[tt] = (f_occ >> tt) & 1u;
     block_reserve_tiles<kRegTiles>(&t.ctr[C_REG], n_occ, ri, trs);
-    block_reserve_tiles<kRegTiles>(&t.ctr[C_PREREG], n_new, pi, trs);
-    block_reserve_tiles<kRegTiles>(&t.ctr[C_PRECHG], n_chg, ci, trs);
     bool overflow = false;
 #pragma unroll
     for (int tt = 0; tt < kRegTiles; tt++) {
         if (n_occ[tt]) {
             if (ri[tt] < t.max_reg) t.reg_occ[ri[tt]] = make_uint2(slot_[tt], nid_[tt]);  // dependants.push_back, grid.hpp:417
-            else overflow = true;
-        }
-        if (n_new[tt]) {
-            if (pi[tt] < t.max_reg) t.prereg_list[pi[tt]] = slot_[tt];
-            else overflow = true;
-        }
-        if (n_chg[tt]) {
-            if (ci[tt] < t.max_reg) t.prechg_list[ci[tt]] = slot_[tt];
             else overflow = true;
         }
     }
@@ -1638,6 +1736,8 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
         }
         if (any) {
             uint32_t e = head;
+            // (Every link is a head that k_buffer / direct_buffer exchanged, i.e. the index of an entry they wrote.  A range check per
+            // hop was measured in round 4: +12 % on this kernel, whose time is the chain of dependent reads; left out.)
             while (e) {
                 const float4 p = t.log_pt[e];
                 const uint32_t rgb = COLOR ? t.log_rgb[e] : 0u;
@@ -1690,27 +1790,6 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
 }
 
 // ---- dependant table rebuild --------------------------------------------------------------------
-__device__ __forceinline__ DepEntry make_dep_entry(const Tables& t, uint32_t nid)
-{
-    const float4 l0 = t.nv_line[2 * (uint64_t)nid], l1 = t.nv_line[2 * (uint64_t)nid + 1];
-    DepEntry e;
-    e.sid = nid;
-    e.ax = l0.x;
-    e.ay = l0.y;
-    e.az = l0.z;
-    e.abx = l0.w;
-    e.aby = l1.x;
-    e.abz = l1.y;
-    e.dd = l1.z;
-    return e;
-}
-// A cell gained its first dependant: set its bit in the brick's flag line (read by k_integrate).
-__device__ __forceinline__ void set_dep_flag(const Tables& t, uint32_t slot)
-{
-    uint64_t plane, bit;
-    slot_plane_bit(slot, plane, bit);
-    atomicOr(reinterpret_cast<unsigned long long*>(&t.nd_mask[plane * 2 + 1]), (unsigned long long)bit);
-}
 __device__ __forceinline__ uint32_t reg_slot(const Tables& t, uint64_t j, uint64_t n_reg) { return j < n_reg ? t.reg_occ[j].x : t.prereg_list[j - n_reg]; }
 
 __global__ __launch_bounds__(256) void k_dep_count(const Tables t, const uint64_t n_reg, const uint64_t n_pre)
@@ -1865,58 +1944,7 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
     if (k + 1 == (uint32_t)((info >> kDepCntShift) & kDepCntMask)) t.dep_tmp[r.x] = kTouchedMark | ((v >> 16) & kDepOldMax);
 }
 
-// Unoccupied cells whose single dependant was set or replaced in this pass (grid.hpp:443-449).
-__device__ __forceinline__ void depinc_pre_body(const Tables& t, const uint64_t n_chg_arg, const uint32_t block)
-{
-    const uint64_t n_chg = n_chg_arg == kCountOnDevice ? min((uint64_t)t.ctr[C_PRECHG], t.max_reg) : n_chg_arg;
-    uint32_t slot_[kListTiles];
-    uint64_t info_[kListTiles];
-    uint32_t f_fresh = 0;
-#pragma unroll
-    for (int tt = 0; tt < kListTiles; tt++) {
-        const uint64_t j = ((uint64_t)block * kListTiles + tt) * 256u + threadIdx.x;
-        slot_[tt] = 0, info_[tt] = 0;
-        if (j < n_chg) {
-            slot_[tt] = t.prechg_list[j];
-            info_[tt] = t.info[slot_[tt]];
-            if (((info_[tt] >> kDepCntShift) & kDepCntMask) == 0) f_fresh |= 1u << tt;
-        }
-    }
-    __shared__ TileReserveScratch<kListTiles> trs;
-    uint32_t n_f[kListTiles];
-    unsigned long long noff[kListTiles];
-#pragma unroll
-    for (int tt = 0; tt < kListTiles; tt++) n_f[tt] = (f_fresh >> tt) & 1u;
-    block_reserve_tiles<kListTiles>(&t.ctr[C_DEP], n_f, noff, trs);
-#pragma unroll
-    for (int tt = 0; tt < kListTiles; tt++) {
-        const uint64_t j = ((uint64_t)block * kListTiles + tt) * 256u + threadIdx.x;
-        if (j >= n_chg) continue;
-        const uint32_t slot = slot_[tt];
-        const uint64_t info = info_[tt];
-        uint64_t off = info >> kDepOffShift;
-        if (f_fresh & (1u << tt)) {
-            off = noff[tt];
-            if (off >= t.max_dep) {
-                atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEP);
-                continue;
-            }
-            t.info[slot] = (info & 3ull) | (1ull << kDepCntShift) | (off << kDepOffShift);
-            set_dep_flag(t, slot);
-        }
-        t.dep[off] = make_dep_entry(t, t.pre_dep[slot]);
-    }
-}
-
-// The two list builders that open the incremental update are independent of each other (occupied targets: count the new
-// entries per cell; unoccupied targets: set / replace their single entry) and share one launch: blocks [0, count_blocks) count,
-// the rest handle the unoccupied targets.  Both only reserve space in dep[] with atomics, in any order.
-__global__ __launch_bounds__(256) void k_depinc_count_pre(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg, const uint64_t n_chg_arg,
-                                                          const uint32_t count_blocks)
-{
-    if (blockIdx.x < count_blocks) depinc_count_body(t, reg_first, n_reg_arg, blockIdx.x);
-    else depinc_pre_body(t, n_chg_arg, blockIdx.x - count_blocks);
-}
+__global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg) { depinc_count_body(t, reg_first, n_reg_arg, blockIdx.x); }
 
 // ---- K6 extract -----------------------------------------------------------------------------------
 // Keys of the records that downloadData would emit: x<xdim && y<ydim && z<zdim (grid.hpp:463-465);
@@ -1996,7 +2024,7 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
         r.rgb = 0;
     } else {
         const float4 l0 = t.nv_line[2 * nid], l1 = t.nv_line[2 * nid + 1];
-        const double ax = l0.x, ay = l0.y, az = l0.z, abx = l0.w, aby = l1.x, abz = l1.y;
+        const double ax = l0.y, ay = l0.z, az = l0.w, abx = l1.x, aby = l1.y, abz = l1.z;
         const double inv = 1.0 / (double)cnt;
         // every projection is a - s*ab (stats.hpp): centroid = a - E[s]*ab, per-axis variance = ab_i^2 * var(s)
         const double em = ((double)s[SW_S] / (double)g.fs_scale) * inv;  // mean of s, or of u = s - 0.5 (stats.hpp)
@@ -2063,12 +2091,12 @@ __global__ __launch_bounds__(256) void k_epoch_export(const GridParams g, const 
 
 __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const Tables t, const EpochRec* __restrict__ in, const uint64_t n)
 {
-    // kRegTiles tiles per workgroup, one occ_list reservation (hot counter: see k_register)
-    uint32_t slot_[kRegTiles];
+    // kImportTiles tiles per workgroup, one occ_list reservation (hot counter: see k_register)
+    uint32_t slot_[kImportTiles];
     uint32_t f_first = 0;
 #pragma unroll
-    for (int tt = 0; tt < kRegTiles; tt++) {
-        const uint64_t j = ((uint64_t)blockIdx.x * kRegTiles + tt) * 256u + threadIdx.x;
+    for (int tt = 0; tt < kImportTiles; tt++) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kImportTiles + tt) * 256u + threadIdx.x;
         bool want = j < n;
         EpochRec r;
         r.key = 0;
@@ -2088,7 +2116,7 @@ __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const 
         if (want) {
             const unsigned long long bit = 1ull << (((y & 7) << 3) | (z & 7));
             const unsigned long long old = atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (x & 7)]), bit);
-            if (!(old & bit)) f_first |= 1u << tt;
+            if (!(old & bit)) f_first |= 1u << tt;  // (joins occ_list: the clean pass this import opens files its pre-dependant, k_materialize_new)
             if (r.first_frame < t.max_frames) {
                 atomicMin(&t.first_frame[slot], r.first_frame);
                 t.frame_vp[3 * (uint64_t)r.first_frame] = r.vx;  // same value from every exporter
@@ -2101,7 +2129,7 @@ __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const 
     unsigned long long oi = block_reserve_n(&t.ctr[C_OCC], (uint32_t)__popc(f_first), brs);
     bool overflow = false;
 #pragma unroll
-    for (int tt = 0; tt < kRegTiles; tt++) {
+    for (int tt = 0; tt < kImportTiles; tt++) {
         if (f_first & (1u << tt)) {
             if (oi < t.max_occ) t.occ_list[oi] = slot_[tt];
             else overflow = true;

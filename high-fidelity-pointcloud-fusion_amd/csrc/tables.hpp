@@ -13,7 +13,8 @@
 //              buf_head u32[4]       heads of the cell's 4 interleaved chains in the point log (VoxelInfo::buffer)
 //              stat_id u32           1-based id of the cell's normal/statistics record, 0 = none
 //              pre_dep u32           the one dependant registered while the cell was unoccupied
-//                                    (grid.hpp:443-449 overwrite semantics: last registrant wins)
+//                                    (grid.hpp:443-449 overwrite semantics: last registrant wins); it becomes the cell's
+//                                    dependant list at the first clean pass after the cell was occupied (kernels.hpp k_materialize_new)
 //              dep_tmp u32           scratch for the dependant-table rebuild
 //   per brick: occ_mask[8] u64       occupancy bits, one u64 per x-plane (bit = ly*8+lz): the 5x5x5 stencil
 //                                    of grid.hpp:334-349 becomes <= 20 u64 loads.
@@ -57,7 +58,7 @@ enum Ctr : int {
     C_NORMALS,      // normal records (ids 1..n)
     C_REG,          // entries in reg_occ
     C_DEP,          // entries in dep[]
-    C_PREREG,       // entries in prereg_list
+    C_PREREG,       // entries in prereg_list: occupied cells whose pre-dependant was filed as their list (kernels.hpp k_materialize_new)
     C_TOUCHED,      // entries in touched_list (rebuild scratch)
     C_CAND,         // candidates of the running clean pass
     C_ERR,          // error bits
@@ -70,7 +71,7 @@ enum Ctr : int {
     C_ROWS,         // rows valid at extract
     C_REPLAY_MEMBER, // buffered points that fell inside a cylinder during clean-time replay
     C_PEND,         // occupied cells still without a normal after the running gate pass
-    C_PRECHG,       // unoccupied cells whose single dependant changed in the running clean pass
+    C_UNUSED19,     // (until round 4: unoccupied cells whose single dependant changed in the running clean pass)
     C_TOUCHED_SINGLE, // host mirror only (sum of word 4 of the striped lines): touched cells of the running pass in single-run bricks
     C_TABLE_MISS,   // work items of k_update_cells that found no slot in the LDS record table (they update HBM directly)
     C_OVF,          // entries in the overflow list of the running integrate launch (k_integrate -> k_integrate_overflow)
@@ -89,6 +90,7 @@ enum ErrBits : uint64_t {
     E_DEPCNT = 128,
     E_FRAME = 256,
     E_OVF = 512,
+    E_CHAIN = 1024,  // a point-log link or run record that names no log entry (internal consistency; the readers stop instead of reading)
 };
 
 struct __attribute__((aligned(32))) DepEntry {  // one dependant of a cell, denormalised for the per-point loop
@@ -118,15 +120,19 @@ struct Tables {
     uint32_t* nv_slot;
     float* nv_c;  // 3 per record
     float* nv_n;  // 3 per record
-    float4* nv_line;  // 2 per record: (a.xyz, ab.x), (ab.y, ab.z, |ab|^2, 0): the per-voxel half of the cylinder test
+    float4* nv_line;  // 2 per record = one DepEntry: (record id, a.xyz), (ab.xyz, |ab|^2): the per-voxel half of the cylinder test
     unsigned long long* stats;
     uint32_t color;   // 1 with HFPF_FLAG_FUSE_COLOR: words 5-7 of a statistics record carry the members' colour sums
     uint32_t test_table_skip;  // tests only (HFPF_TEST_TABLE_SKIP=1): records with an odd id bypass the LDS record tables, as if they were full
     uint64_t* nd_mask;  // per brick and x-plane, 2 words: normal_found bits, has-dependants bits of the plane's 64 cells
     uint2* reg_occ;
     DepEntry* dep;
+    // dep[] and nv_line (one 32-byte entry per normal record, same layout; allocated behind dep[]) addressed as ONE array of entries:
+    // *_first = where each starts in it (in entries).  k_update_cells keeps a 40-bit entry index per cell, so the list of a cell --
+    // entries of dep[], or the record line of its pre-dependant -- is read the same way.
+    const DepEntry* ent_base;
+    uint64_t ent_dep_first, ent_nv_first;
     uint32_t* prereg_list;
-    uint32_t* prechg_list;
     uint32_t* touched_list;
     // per brick: the point-log run k_buffer appended last (first entry, length) and how many appends the brick has seen (+ 0x100 for
     // every entry that reached the log outside a run).  A brick with exactly ONE run holds all its buffered points contiguously:

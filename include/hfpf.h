@@ -137,7 +137,11 @@ int hfpf_get_dims(const hfpf_handle* h, int32_t dims[3], double* resolution);
  * The buffer is copied before the call returns.  Frame ids count up from 0 per handle.
  * The frame's kernels are launched at once when the engine's stream is idle; while it is busy with earlier frames the frame
  * waits (already uploading) and is launched together with the frames behind it, at most HFPF_HOST_BATCH (default 4) per launch.
- * Any other call on the handle launches what is waiting first; an error of a deferred launch is returned by that call. */
+ * Any other call on the handle launches what is waiting first; an error of a deferred launch is returned by that call.
+ * Deferred errors: HFPF_OK means "accepted".  A pool that overflows on the device while the frame's kernels run (HFPF_ERR_CAPACITY)
+ * is noticed at the handle's next counter read-back -- hfpf_clean, hfpf_extract, hfpf_sync, hfpf_get_counters -- and returned by
+ * that call; the handle then refuses work (HFPF_ERR_STATE) until hfpf_clear.  Frames accepted after the failure and not yet
+ * launched are dropped, and the call that finds them waiting says so with HFPF_ERR_STATE. */
 int hfpf_integrate(hfpf_handle* h, const void* base, uint32_t n_points, uint32_t point_step, uint32_t off_x,
                    uint32_t off_y, uint32_t off_z, uint32_t off_rgb, const double pose_3x4[12]);
 
@@ -160,7 +164,14 @@ int hfpf_integrate_device(hfpf_handle* h, const void* dev_base, uint32_t n_frame
 /* OccupancyGrid::state_changed (grid.hpp:110; read at node.cpp:306). Returns 0/1, or a negative status. */
 int hfpf_is_dirty(hfpf_handle* h);
 /* OccupancyGrid::updateThicknessVectors<N,K> (grid.hpp:311-454; call sites node.cpp:311,317).
- * Candidates are processed in canonical ascending (x,y,z) order. */
+ * The result is that of the reference walking its candidates in canonical ascending (x,y,z) order: "the last registrant wins" on
+ * an unoccupied cell (grid.hpp:443-449) goes to the candidate with the largest (x,y,z) key of the pass.  The records themselves
+ * are numbered in Z-order of their cells inside a pass (neighbouring records = neighbouring cells); DESIGN.md section 3.
+ * Deferred errors: a SMALL pass (fewer than 2^21 / (2K+1) candidate cells) is enqueued to its end and HFPF_OK returned without
+ * waiting for it; a pool that overflows inside such a pass (HFPF_ERR_CAPACITY: normal records, registrations, dependant table)
+ * is returned by the next call that reads the counters back (this one included, on its next invocation), and the handle then
+ * refuses work until hfpf_clear.  Integrate calls enqueued in between run on the tables as the failed pass left them; their
+ * results are discarded with the handle's state at hfpf_clear.  HFPF_CLEAN_NOWAIT=0 makes every pass wait and report itself. */
 int hfpf_clean(hfpf_handle* h);
 
 /* OccupancyGrid::downloadData (grid.hpp:456-488; call site node.cpp:398) split in two: the ordered

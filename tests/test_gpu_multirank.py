@@ -256,8 +256,59 @@ def test_rccl_world_size_one_poisoned_rank_returns_instead_of_blocking(hfpf_mod,
             g.extract()
 
 
-def _two_proc_failing_worker(rank, world, port, q, scene_kw):
-    """Like _two_proc_worker, but rank 1's point log is far too small: its export fails at the first collective clean."""
+def _fail_by_deferred_host_frame(g, hfpf_mod, sc):
+    """Leaves the handle (created with max_frames = 50) with a host frame that is WAITING for its launch and whose launch must fail
+    (frame id 50 = max_frames).  hfpf_integrate defers a frame's launch while the engine's stream is busy behind an earlier host
+    frame (HFPF_HOST_BATCH): host frame 0 sets the staging ring up; 48 device frames without a bin plan (every point through the
+    overflow list: milliseconds of kernels, nothing the host waits for) keep the stream busy; host frame 49 is launched behind
+    them; host frame 50 finds that launch unfinished and stays pending -- the next call on the handle (the clean pass, as in the
+    node) flushes it and gets the error.  Should a very slow host see the stream drained already, the error comes out of
+    hfpf_integrate itself and only the frame is dropped; the callers below accept either."""
+    big = scenes.Scene(48, 640, 480, sc.resolution, bbox=sc.bbox)
+    fb = 640 * 480 * 16
+    dev = g.device_alloc(48 * fb)
+    for f in range(48):
+        g.device_upload(dev + f * fb, big.frame(f))
+    small = sc.frame(0)
+    g.integrate(small, sc.poses[0])  # frame id 0
+    g.sync()
+    g.integrate_device(dev, 48, fb, 640 * 480, np.stack(big.poses))  # ids 1..48
+    deferred = True
+    try:
+        g.integrate(small, sc.poses[0])  # id 49: launched behind the batch
+        g.integrate(small, sc.poses[0])  # id 50 = max_frames: waits, fails when flushed
+    except hfpf_mod.HfpfError as e:
+        assert e.code == -3 and "max_frames" in str(e)
+        deferred = False
+    return dev, deferred
+
+
+def test_rccl_world_size_one_deferred_host_frame_failure_goes_through_the_consensus(hfpf_mod, synth_mod):
+    """Round-3 review: hfpf_clean / hfpf_extract returned the error of a deferred host-frame launch BEFORE the status gather, so a
+    rank failing that way would have left its peers in ncclAllGather.  The failure is now folded into the status word.  At the only
+    world size RCCL can form here: the failing rank comes back from clean and extract with its error (not a hang), is poisoned,
+    and hfpf_clear revives it."""
+    sc = scenes.Scene(1, 160, 120, 0.001, fx=615.0)
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **dict(SMALL, max_frames=50, max_log_points=24 << 20, max_normals=4 << 20)) as g:
+        g.dist_init_rccl(0, 1, hfpf_mod.dist_unique_id())
+        dev, deferred = _fail_by_deferred_host_frame(g, hfpf_mod, sc)
+        assert deferred, "the host frame was launched at once: the stream was idle (box too slow for this test's timing assumption)"
+        codes = []
+        for call in (g.clean, g.extract, g.clean):
+            with pytest.raises(hfpf_mod.HfpfError) as e:
+                call()
+            codes.append(e.value.code)
+        assert codes == [-3, -5, -5], codes  # capacity where the frame was still waiting, "failed earlier" after that
+        g.clear()
+        g.device_free(dev)
+        g.integrate(sc.frame(0), sc.poses[0])
+        g.clean()
+        assert len(g.extract()) >= 0
+
+
+def _two_proc_failing_worker(rank, world, port, q, scene_kw, mode="log"):
+    """Like _two_proc_worker, but rank 1 fails in front of the first collective clean: its point log is far too small (mode "log":
+    the export finds the overflow), or a host frame whose launch was deferred fails when the clean flushes it (mode "deferred")."""
     try:
         import os
         import sys
@@ -274,10 +325,17 @@ def _two_proc_failing_worker(rank, world, port, q, scene_kw):
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         sc = scenes.Scene(seed=0xF051 + 7919 * rank, pose_seed=0x5E3 + 104729 * rank, **scene_kw)
-        caps = dict(SMALL, max_log_points=4096) if rank == 1 else SMALL
+        caps = SMALL
+        if rank == 1:
+            caps = dict(SMALL, max_log_points=4096) if mode == "log" else dict(SMALL, max_frames=50, max_log_points=24 << 20, max_normals=4 << 20)
         g = hfpf.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **caps)
         g.attach_transport(hfpf_dist.HostStagedTransport(dist))
-        g.integrate(sc.frame(0), sc.poses[0])
+        if rank == 1 and mode == "deferred":
+            _, was_deferred = _fail_by_deferred_host_frame(g, hfpf, sc)
+            if not was_deferred:
+                raise RuntimeError("the host frame was launched at once: the stream was idle (timing assumption of the test)")
+        else:
+            g.integrate(sc.frame(0), sc.poses[0])
         out = []
         for call in (g.clean, g.extract):
             try:
@@ -294,9 +352,11 @@ def _two_proc_failing_worker(rank, world, port, q, scene_kw):
         q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
 
 
-def test_two_processes_failure_on_one_rank_stops_both(hfpf_mod, synth_mod):
-    """Two OS processes on the GPU over the gloo host-staged transport, rank 1 overflowing its point log: both must return an
-    error from the collective clean and from the collective extract; a hang fails the test through its timeout."""
+@pytest.mark.parametrize("mode", ["log", "deferred"])
+def test_two_processes_failure_on_one_rank_stops_both(hfpf_mod, synth_mod, mode):
+    """Two OS processes on the GPU over the gloo host-staged transport, rank 1 overflowing its point log (mode "log") or failing
+    the deferred launch of a host frame (mode "deferred": what the real node's hfpf_integrate path can do to a clean): both ranks
+    must return an error from the collective clean and from the collective extract; a hang fails the test through its timeout."""
     import multiprocessing as mp
     import queue as queue_mod
     import socket
@@ -307,7 +367,7 @@ def test_two_processes_failure_on_one_rank_stops_both(hfpf_mod, synth_mod):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_proc_failing_worker, args=(r, 2, port, q, kw)) for r in range(2)]
+    procs = [ctx.Process(target=_two_proc_failing_worker, args=(r, 2, port, q, kw, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}

@@ -255,3 +255,42 @@ def test_host_frames_batched_over_several_copy_streams_equal_device_frames(hfpf_
         assert got.tobytes() == ref.tobytes(), "host frames (batch %s, %s copy streams, pinned=%s) differ from device frames" % (host_batch, copy_streams, pinned)
         for k in keys:
             assert ctr[k] == ref_ctr[k], k
+
+
+def _plane_frame(offset_along_normal, n=200, half=0.02, seed=1):
+    """A tilted planar patch z = 0.4 + 0.5 x + 0.3 y (camera frame = fusion frame: identity pose), shifted along its unit normal,
+    as one packed XYZRGB frame: n x n samples, jittered by a few micrometres so that no point sits on a voxel boundary."""
+    rng = np.random.default_rng(seed)
+    u = np.linspace(-half, half, n, dtype=np.float64)
+    x, y = np.meshgrid(u, u, indexing="ij")
+    nrm = np.array([-0.5, -0.3, 1.0]) / np.sqrt(0.25 + 0.09 + 1.0)
+    pts = np.stack([x, y, 0.4 + 0.5 * x + 0.3 * y], -1).reshape(-1, 3) + offset_along_normal * nrm + rng.uniform(-3e-6, 3e-6, (n * n, 3))
+    rec = np.zeros((n * n, 4), np.float32)
+    rec[:, :3] = pts
+    rec[:, 3] = np.frombuffer(np.full(n * n, 0x00808080, np.uint32).tobytes(), np.float32)
+    return rec.tobytes()
+
+
+def test_registration_contest_on_unoccupied_cells_follows_the_key_order(oracle_mod, hfpf_mod, synth_mod):
+    """'The last registrant wins' on an unoccupied cell (OccupancyGrid.hpp:443-449) with record ids that follow the Z-order of a pass
+    while the contest is about the canonical (x, y, z) order (round-3 advisor finding).  A tilted plane: the normals lean in x
+    and y, so the +-3-step walks of neighbouring voxels -- which differ in x AND y, i.e. pairs whose Morton order and key order
+    disagree are common -- end on the same unoccupied cells one to three cells off the surface.  A second frame then puts its points
+    exactly there (the plane shifted 2.2 mm along its normal): every one of them updates the ONE registrant its cell kept, so the
+    members-per-voxel counts of the first plane's voxels say who won each contest.  Compared with the oracle, which walks the
+    candidates in ascending key order.  (A build in which the atomicMax over the Z-order ids alone settles the contest -- the key
+    comparison compiled out -- fails this test: counts differ at hundreds of rows; checked once on the GPU box in round 4.)"""
+    pose = synth_mod.identity_pose()
+    frames = [_plane_frame(0.0), _plane_frame(0.0022, seed=2)]
+    og = oracle_mod.OracleGrid(resolution=0.001, bbox=scenes.BBOX_1M)
+    with hfpf_mod.OccupancyGrid(resolution=0.001, bbox=scenes.BBOX_1M, **SMALL) as eg:
+        for fr in frames:
+            og.capture(fr, pose)
+            og.clean()
+            eg.integrate(fr, pose)
+            eg.clean()
+        ref, got = og.extract(), eg.extract()
+        ctr = eg.counters()
+    og.close()
+    assert len(ref) > 2000 and ctr["dep_pairs_member"] > 20000  # the second plane's points found registrants on their (formerly unoccupied) cells
+    scenes.compare_rows(ref, got)

@@ -20,4 +20,5 @@ tools/pmc_passes.sh ${TAG}_sq "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_C
   "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" || exit 1
 python3 tools/pmc_table.py gpurun_out/${TAG}_mem k_integrate k_update k_replay k_register k_depinc k_normal k_buffer > gpurun_out/${TAG}_mem_counters.md
 python3 tools/pmc_table.py gpurun_out/${TAG}_sq k_integrate k_update k_replay k_register k_depinc k_normal k_buffer > gpurun_out/${TAG}_sq_counters.md
+python3 tools/pmc_summary.py gpurun_out/${TAG}_mem gpurun_out/${TAG}_pmc_hot_path gpurun_out/${TAG}_sq --workload c3 > /dev/null
 echo "c3 profiles done"

@@ -2,9 +2,10 @@
 """Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh (one counter set per pass, as MI355X_MICROARCH.md prescribes) for
 the integrate hot path: k_integrate (decode / clip / transform / insert / park) + k_update (per-brick LDS accumulation).
 
-usage: python tools/pmc_summary.py gpurun_out/<mem prefix> profiles/r03_pmc_hot_path [gpurun_out/<sq prefix>]
-(the optional third argument adds the SQ counters of k_update_cells -- instruction counts, active lanes, LDS bank conflicts --
-as section "sq", which bench.py turns into roofline.compute)
+usage: python tools/pmc_summary.py gpurun_out/<mem prefix> profiles/r04_pmc_hot_path [gpurun_out/<sq prefix>] [--workload c3]
+(the optional third argument adds the SQ counters of k_update_cells and k_integrate -- instruction counts, active lanes, LDS bank
+conflicts -- as section "sq", which bench.py turns into roofline.compute and roofline.compute_integrate; --workload c3: the passes
+ran `bench.py --workload c3`, i.e. 100 frames of 2048x1536 in calls of 15 -- the same dispatch pattern at another size)
 
 Each pass ran `bench.py --repeats 1 --warmup 0 --cpu-sample 0 --host-path-frames 0`: the 1000-frame configs[1] stream, one
 hfpf_integrate_device call per clean epoch.  k_integrate dispatches: #0 = the dry run of the session's first 8 frames (bin
@@ -57,13 +58,21 @@ def series(per, kernel, counter):
 
 
 def sq_section(sq_prefix):
-    """Means over the steady launches of k_update_cells (all but the last, 100-frame one) + the pairs one such launch tests."""
+    """Means over the steady launches of k_update_cells (all but the last, shorter one) + the pairs one such launch tests, and
+    over the steady launches of k_integrate (#2..#6: behind the dry run and the first epoch, in front of the shorter tail)."""
     per = load(sq_prefix)
     out = {}
     for c, d in per["k_update"].items():
         v = [d[i] for i in sorted(d)]
         v = v[:-1] if len(v) > 1 else v
         out[c] = sum(v) / len(v)
+    integ = {}
+    for c, d in per["k_integrate"].items():
+        v = [d[i] for i in sorted(d)][2:7]
+        if v:
+            integ[c] = sum(v) / len(v)
+    if integ.get("SQ_THREAD_CYCLES_VALU") and integ.get("SQ_ACTIVE_INST_VALU"):
+        integ["active_lane_fraction"] = integ["SQ_THREAD_CYCLES_VALU"] / (integ["SQ_ACTIVE_INST_VALU"] * 64.0)
     pairs = None
     for f in sorted(glob.glob(sq_prefix + "_*.json")):
         try:
@@ -74,14 +83,28 @@ def sq_section(sq_prefix):
             continue
     if out.get("SQ_THREAD_CYCLES_VALU") and out.get("SQ_ACTIVE_INST_VALU"):
         out["active_lane_fraction"] = out["SQ_THREAD_CYCLES_VALU"] / (out["SQ_ACTIVE_INST_VALU"] * 64.0)
-    return {"k_update": out, "pairs_per_launch": pairs}
+    return {"k_update": out, "k_integrate": integ, "pairs_per_launch": pairs}
 
 
 def main():
-    prefix, out = sys.argv[1], sys.argv[2]
+    global FRAMES_PER_LAUNCH, NPTS
+    argv = list(sys.argv[1:])
+    if "--workload" in argv:
+        i = argv.index("--workload")
+        if argv[i + 1] == "c3":
+            FRAMES_PER_LAUNCH, NPTS = 15, 2048 * 1536
+        del argv[i:i + 2]
+    prefix, out = argv[0], argv[1]
     per = load(prefix)
     mean = lambda v: sum(v) / len(v) if v else 0.0
-    in_bbox_frac = 0.826  # points_in_bbox / points_presented of the bench stream (bench.py counters)
+    in_bbox_frac = 0.826  # points_in_bbox / points_presented of the configs[1] stream; replaced by the passes' own bench line when there is one
+    for f in sorted(glob.glob(prefix + "_*.json")):
+        try:
+            c = json.loads(open(f).read().strip().splitlines()[-1])["counters"]
+            in_bbox_frac = c["points_in_bbox"] / float(c["points_presented"])
+            break
+        except Exception:
+            continue
     pts = FRAMES_PER_LAUNCH * NPTS
     res = {"source_sha": source_sha(), "points_per_launch": pts, "frames_per_launch": FRAMES_PER_LAUNCH,
            "source": "rocprofv3 --pmc, separate passes (tools/pmc_passes.sh), bench.py --repeats 1 --warmup 0"}
@@ -113,8 +136,9 @@ def main():
             "traffic_bytes_per_point": traffic / pts,
             "algorithmic_bytes_per_launch": 32 * pts,
         }
-    if len(sys.argv) > 3:
-        res["sq"] = sq_section(sys.argv[3])
+    res["in_bbox_fraction"] = in_bbox_frac
+    if len(argv) > 2:
+        res["sq"] = sq_section(argv[2])
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
         f.write("# Integrate hot path: memory-side counters (rocprofv3 --pmc, one counter set per pass)\n\n")
