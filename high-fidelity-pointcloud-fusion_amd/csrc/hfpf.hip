@@ -263,6 +263,7 @@ struct hfpf_handle {
     void* rccl_lib = nullptr;
     void* comm = nullptr;  // ncclComm_t
     uint64_t occ_exported = 0;  // occ_list entries already exchanged
+    uint64_t frames_exported = 0, frames_seen = 0;  // frame_list entries already exchanged / as of the last export
     uint64_t ex_cap_records = 0;  // records the exchange buffers hold per rank; kept EQUAL on every rank (same initial value, same growth rule)
     DevBuf ex_send, ex_recv, ex_counts, stats_total;
     unsigned long long* h_counts = nullptr;  // pinned, world entries
@@ -586,6 +587,7 @@ int reset_state(hfpf_handle* h)
     h->poisoned = false;
     h->poison_msg.clear();
     h->occ_exported = 0;
+    h->frames_exported = h->frames_seen = 0;
     h->next_frame_id = 0;
     return HFPF_OK;
 }
@@ -650,6 +652,7 @@ int alloc_tables(hfpf_handle* h)
     ALLOC(run_cnt, t.max_bricks + 2);
     ALLOC(cand_key, t.max_occ, 0, false);
     ALLOC(frame_vp, 3 * t.max_frames);
+    ALLOC(frame_list, t.max_frames, 0, false);
     ALLOC(ctr, C_COUNT);
     ALLOC(log_ctr, kLogRegions * 16);
     ALLOC(bin_fill, 2 * (t.max_bricks + 2));
@@ -1090,12 +1093,17 @@ int epoch_export_locked(hfpf_handle* h, uint64_t* n_out, uint64_t min_capacity_r
     if (rc) return rc;
     if ((rc = check_device_errors(h))) return rc;
     const uint64_t n_occ = std::min<uint64_t>(h->h_ctr[C_OCC], h->t.max_occ);
-    const uint64_t n_new = n_occ - std::min(n_occ, h->occ_exported);
+    const uint64_t n_cells = n_occ - std::min(n_occ, h->occ_exported);
+    const uint64_t n_fr_all = std::min<uint64_t>(h->h_ctr[C_FRAMES], h->t.max_frames);
+    const uint64_t n_frames = n_fr_all - std::min(n_fr_all, h->frames_exported);
+    const uint64_t n_new = n_cells + 2 * n_frames;  // one record per cell, two per frame (its viewpoint)
     if ((rc = scratch(h, h->ex_send, std::max<uint64_t>(std::max(n_new, min_capacity_records), 1) * sizeof(EpochRec)))) return rc;
     if (n_new) {
-        hipLaunchKernelGGL(k_epoch_export, dim3(blocks_for(n_new, 256)), dim3(256), 0, h->stream, h->g, h->t, h->occ_exported, n_occ, (EpochRec*)h->ex_send.p);
+        hipLaunchKernelGGL(k_epoch_export, dim3(blocks_for(n_new, 256)), dim3(256), 0, h->stream, h->g, h->t, h->occ_exported, n_cells, h->frames_exported, n_frames,
+                           (EpochRec*)h->ex_send.p);
         HIPCHK(h, hipGetLastError());
     }
+    h->frames_seen = n_fr_all;  // (the clean pass that follows the exchange marks them exchanged, like the cells)
     *n_out = n_new;
     return HFPF_OK;
 }
@@ -1235,6 +1243,7 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     const uint64_t n_normals = h->h_ctr[C_NORMALS];
     const uint64_t n_pend = h->pend_valid ? h->h_ctr[C_PEND] : 0;  // cells the previous pass left without a normal (pend_a)
     h->occ_exported = n_occ;  // everything occupied so far (locally or imported) has been exchanged
+    h->frames_exported = std::max(h->frames_exported, h->frames_seen);  // ... and the viewpoints of the frames the last export covered
     h->dirty = false;  // state_changed = false, grid.hpp:313
     h->clean_passes++;
 
@@ -1268,11 +1277,12 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     // device counters (kCountOnDevice), and the host picks the values up at the read-back after them.
     const uint64_t reg_ub = (2ull * (uint64_t)h->g.K + 1ull) * n_in;
     // Incremental update of the dependant table, or a compacting rebuild?  A conservative space estimate decides (C_DEP as of the
-    // read-back above: nothing has changed it since).  What one incremental update can take from dep[]: every relocated list (at
-    // most all live entries: registrations + filed pre-dependants so far), two entries per registration bound of this pass, and
+    // read-back above: nothing has changed it since).  What one incremental update can take from dep[]: a block of the next
+    // power-of-two capacity for every list that outgrows its own (kernels.hpp dep_capacity) -- below twice its new length, i.e.
+    // at most twice (all live entries: registrations + filed pre-dependants so far, + the registration bound of this pass) -- and
     // one entry per cell occupied since the last pass (the pre-dependants filed at the head of the pass).
     const uint64_t live_ub = std::min<uint64_t>(h->h_ctr[C_REG], t.max_reg) + std::min<uint64_t>(h->h_ctr[C_PREREG], t.max_reg);
-    bool full = h->h_ctr[C_DEP] + live_ub + 3 * reg_ub + n_new_occ > t.max_dep;
+    bool full = h->h_ctr[C_DEP] + 2 * live_ub + 2 * reg_ub + n_new_occ > t.max_dep;
     // sentinels + the pass's list counters + the pre-dependants of the cells occupied since the last pass become their lists
     hipLaunchKernelGGL(k_clean_begin, dim3(blocks_for(n_in, 256)), dim3(256), 0, s, t, n_in, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, full ? 1u : 0u);
     launch_gate(h, (const uint32_t*)h->pend_a.p, n_pend, (const uint32_t*)(t.occ_list + h->gate_done), n_new_occ, (uint32_t*)h->pend_b.p);
@@ -1336,7 +1346,8 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     }
     if (full) {
         const uint64_t n_all = n_reg + n_pre;
-        if (n_all > t.max_dep) return fail(h, HFPF_ERR_CAPACITY, "dependant table: %llu entries > %llu", (unsigned long long)n_all, (unsigned long long)t.max_dep);
+        if (2 * n_all > t.max_dep)  // (lists own power-of-two blocks: below twice their length)
+            return fail(h, HFPF_ERR_CAPACITY, "dependant table: %llu entries do not fit %llu with their blocks", (unsigned long long)n_all, (unsigned long long)t.max_dep);
         // touched_list holds one entry per distinct cell among the n_all registrations: every normal record registers on at most
         // 2K+1 cells, so n_reg + n_pre <= max_normals * (2K+1) = max_reg = max_touched
         if (n_all > h->max_touched) return fail(h, HFPF_ERR_CAPACITY, "registrations: %llu > %llu", (unsigned long long)n_all, (unsigned long long)h->max_touched);

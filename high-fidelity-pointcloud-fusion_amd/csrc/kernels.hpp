@@ -356,10 +356,15 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
         for (int k = 0; k < 12; k++) T[k] = poses[12 * f + k];
         const uint32_t fid = frame_ids[f];
         if (i == 0) {  // viewpoint = float(translation), node.cpp:290
-            float* vp = (BIN ? kernarg_tables() : t).frame_vp + 3 * (uint64_t)fid;
+            const Tables& tr = BIN ? kernarg_tables() : t;
+            float* vp = tr.frame_vp + 3 * (uint64_t)fid;
             vp[0] = (float)T[3];
             vp[1] = (float)T[7];
             vp[2] = (float)T[11];
+            if (!probe) {  // the frames this rank has integrated: what the next epoch exchange sends viewpoints for
+                const unsigned long long fi = atomicAdd(&tr.ctr[C_FRAMES], 1ull);
+                if (fi < tr.max_frames) tr.frame_list[fi] = fid;  // (ids are below max_frames: the list only fills up when ids repeat, and then they are in it)
+            }
         }
         const uint8_t* __restrict__ base = frames + (uint64_t)f * frame_stride;
         bool act = i < n_pts;
@@ -1792,6 +1797,13 @@ __global__ __launch_bounds__(256) void k_replay(const GridParams g, const Tables
 // ---- dependant table rebuild --------------------------------------------------------------------
 __device__ __forceinline__ uint32_t reg_slot(const Tables& t, uint64_t j, uint64_t n_reg) { return j < n_reg ? t.reg_occ[j].x : t.prereg_list[j - n_reg]; }
 
+// A cell's dependant list owns a power-of-two number of entries (1, 2, 4, ...: dep_capacity of its length).  A clean pass that
+// extends the list appends IN PLACE while the new length fits and relocates it -- into a block of the next capacity -- only when it
+// does not, so a list that grows by an entry or two per pass moves a logarithmic number of times instead of once per pass (on the
+// 0.5 mm workload a touched cell holds ~8 entries: relocating them all every pass was most of k_depinc_offsets' 32-byte traffic).
+// Every writer of info words allocates by this rule: k_depinc_offsets, the compacting rebuild (k_dep_offsets), k_clean_begin (1).
+__device__ __forceinline__ uint32_t dep_capacity(uint32_t cnt) { return cnt <= 1u ? cnt : 1u << (32 - __clz((int)(cnt - 1u))); }
+
 __global__ __launch_bounds__(256) void k_dep_count(const Tables t, const uint64_t n_reg, const uint64_t n_pre)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1812,12 +1824,12 @@ __global__ __launch_bounds__(256) void k_dep_offsets(const Tables t, const uint6
     const bool act = j < n_touched;
     const uint32_t slot = act ? t.touched_list[j] : 0u;
     uint32_t cnt = act ? t.dep_tmp[slot] : 0u;
-    const unsigned long long off = wave_reserve_n(&t.ctr[C_DEP], cnt);
-    if (!act) return;
     if (cnt > kDepCntMask) {
         atomicOr(&t.ctr[C_ERR], (unsigned long long)E_DEPCNT);
         cnt = (uint32_t)kDepCntMask;
     }
+    const unsigned long long off = wave_reserve_n(&t.ctr[C_DEP], dep_capacity(cnt));
+    if (!act) return;
     t.info[slot] = (t.info[slot] & 3ull) | ((uint64_t)cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
     if (cnt) set_dep_flag(t, slot);
     t.dep_tmp[slot] = 0;
@@ -1878,41 +1890,46 @@ __device__ __forceinline__ void depinc_count_body(const Tables& t, const uint64_
 __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched_arg)
 {
     const uint64_t n_touched = n_touched_arg == kCountOnDevice ? (uint64_t)t.ctr[C_TOUCHED] : n_touched_arg;
-    uint32_t slot_[kListTiles], old_cnt_[kListTiles], new_cnt_[kListTiles];
+    uint32_t slot_[kListTiles], old_cnt_[kListTiles], new_cnt_[kListTiles], take_[kListTiles];
     uint64_t info_[kListTiles];
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
         const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
-        slot_[tt] = 0, old_cnt_[tt] = 0, new_cnt_[tt] = 0, info_[tt] = 0;
+        slot_[tt] = 0, old_cnt_[tt] = 0, new_cnt_[tt] = 0, take_[tt] = 0, info_[tt] = 0;
         if (j < n_touched) {
             slot_[tt] = t.touched_list[j];
             info_[tt] = t.info[slot_[tt]];
             old_cnt_[tt] = (uint32_t)((info_[tt] >> kDepCntShift) & kDepCntMask);
             new_cnt_[tt] = old_cnt_[tt] + t.dep_tmp[slot_[tt]];
+            // the list stays where it is while it fits the block it owns (dep_capacity); otherwise it moves into a block of the next capacity
+            if (new_cnt_[tt] > dep_capacity(old_cnt_[tt])) take_[tt] = dep_capacity(min(new_cnt_[tt], (uint32_t)kDepCntMask));
         }
     }
     __shared__ TileReserveScratch<kListTiles> trs;
     unsigned long long off_[kListTiles];
     uint32_t n_single = 0;
-    block_reserve_tiles<kListTiles>(&t.ctr[C_DEP], new_cnt_, off_, trs);  // one atomic per workgroup; lists of neighbouring cells stay adjacent
+    block_reserve_tiles<kListTiles>(&t.ctr[C_DEP], take_, off_, trs);  // one atomic per workgroup; lists of neighbouring cells stay adjacent
 #pragma unroll
     for (int tt = 0; tt < kListTiles; tt++) {
         const uint64_t j = ((uint64_t)blockIdx.x * kListTiles + tt) * 256u + threadIdx.x;
         if (j >= n_touched) continue;
         const uint32_t slot = slot_[tt], old_cnt = old_cnt_[tt], new_cnt = new_cnt_[tt];
         const uint64_t info = info_[tt], old_off = info >> kDepOffShift;
-        const unsigned long long off = off_[tt];
+        const bool moves = take_[tt] != 0;
+        const unsigned long long off = moves ? off_[tt] : old_off;
         // No room left in dep[], or an old list too long for the 15-bit note of the cursor word (kDepOldMax; the info word itself
         // counts to 65535): E_DEP, which the host answers with the compacting rebuild (k_dep_*, no such limit).  More than 65535
         // entries on one cell fit nowhere: E_DEPCNT, a capacity error.  (A cell's registrants all lie within K cells of it along
         // their normals, a few hundred voxels at most, so neither limit is reachable by a real scene.)
-        if (off + new_cnt > t.max_dep || new_cnt > kDepCntMask || old_cnt > kDepOldMax) {
+        if ((moves && off + take_[tt] > t.max_dep) || new_cnt > kDepCntMask || old_cnt > kDepOldMax) {
             atomicOr(&t.ctr[C_ERR], (unsigned long long)(new_cnt > kDepCntMask ? E_DEPCNT : E_DEP));
             t.dep_tmp[slot] = kDepPoison;  // k_depinc_fill skips this cell
             continue;
         }
         n_single += t.run_cnt[slot >> 9] == 1u ? 1u : 0u;
-        for (uint32_t k = 0; k < old_cnt; k++) t.dep[off + k] = t.dep[old_off + k];
+        if (moves) {
+            for (uint32_t k = 0; k < old_cnt; k++) t.dep[off + k] = t.dep[old_off + k];
+        }
         t.info[slot] = (info & 3ull) | ((uint64_t)new_cnt << kDepCntShift) | ((uint64_t)off << kDepOffShift);
         if (old_cnt == 0 && new_cnt) set_dep_flag(t, slot);
         t.dep_tmp[slot] = (old_cnt << 16) | old_cnt;  // old length | append cursor
@@ -2061,32 +2078,47 @@ __global__ __launch_bounds__(256) void k_extract_rows(const GridParams g, const 
 // smallest frame id that touched it (the viewpoint latch).  Each rank exports the cells IT occupied since
 // the last exchange and imports everybody else's; normals and registrations are then computed redundantly
 // and deterministically on every rank, while buffers and statistic sums stay private partial state.
-struct __attribute__((aligned(32))) EpochRec {
-    uint64_t key;
-    uint32_t first_frame;
-    float vx, vy, vz;  // viewpoint of that frame (ranks only know their own frames' poses)
-    uint32_t pad[2];
+// One 16-byte record per newly occupied cell (key, smallest frame id that touched it) and TWO per frame the rank has integrated since
+// the last exchange (the frame's viewpoint: ranks only know their own frames' poses, and a cell's latch may name anybody's frame).
+// Until round 4 every cell record carried its frame's viewpoint: 32 bytes a cell, 338 MB received per rank in the first epoch of
+// eight cameras (profiles/r04_virtual_ranks.md); the viewpoints now travel once per frame.
+struct __attribute__((aligned(16))) EpochRec {
+    uint64_t key;  // cell key (below 2^63), or kEpochFrame | half << 62 | frame id
+    union {
+        struct {
+            uint32_t first_frame, pad;
+        };
+        struct {
+            float a, b;  // half 0: viewpoint x, y; half 1: viewpoint z, 0
+        };
+    };
 };
-static_assert(sizeof(EpochRec) == 32, "EpochRec is 32 bytes");
+static_assert(sizeof(EpochRec) == 16, "EpochRec is 16 bytes");
+constexpr uint64_t kEpochFrame = 1ull << 63, kEpochFrameHalf = 1ull << 62;
 
-__global__ __launch_bounds__(256) void k_epoch_export(const GridParams g, const Tables t, const uint64_t first, const uint64_t n_occ, EpochRec* __restrict__ out)
+// Records [0, n_cells): the cells occ_list[first .. first + n_cells); behind them two records per frame of frame_list[frame_first .. + n_frames).
+__global__ __launch_bounds__(256) void k_epoch_export(const GridParams g, const Tables t, const uint64_t first, const uint64_t n_cells, const uint64_t frame_first,
+                                                      const uint64_t n_frames, EpochRec* __restrict__ out)
 {
-    const uint64_t j = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_occ) return;
-    const uint32_t slot = t.occ_list[j];
-    int32_t x, y, z;
-    slot_coords(g, t, slot, x, y, z);
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cells + 2 * n_frames) return;
     EpochRec r;
-    r.key = make_key(g, x, y, z);
-    r.first_frame = t.first_frame[slot];
-    r.vx = r.vy = r.vz = 0.f;
-    if (r.first_frame < t.max_frames) {
-        r.vx = t.frame_vp[3 * (uint64_t)r.first_frame];
-        r.vy = t.frame_vp[3 * (uint64_t)r.first_frame + 1];
-        r.vz = t.frame_vp[3 * (uint64_t)r.first_frame + 2];
+    if (j < n_cells) {
+        const uint32_t slot = t.occ_list[first + j];
+        int32_t x, y, z;
+        slot_coords(g, t, slot, x, y, z);
+        r.key = make_key(g, x, y, z);
+        r.first_frame = t.first_frame[slot];
+        r.pad = 0;
+    } else {
+        const uint64_t k = j - n_cells;
+        const uint32_t fid = t.frame_list[frame_first + (k >> 1)];
+        const uint32_t half = (uint32_t)(k & 1u);
+        r.key = kEpochFrame | (half ? kEpochFrameHalf : 0ull) | fid;
+        r.a = t.frame_vp[3 * (uint64_t)fid + 2 * half];
+        r.b = half ? 0.f : t.frame_vp[3 * (uint64_t)fid + 1];
     }
-    r.pad[0] = r.pad[1] = 0;
-    out[j - first] = r;
+    out[j] = r;
 }
 
 __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const Tables t, const EpochRec* __restrict__ in, const uint64_t n)
@@ -2101,12 +2133,25 @@ __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const 
         EpochRec r;
         r.key = 0;
         r.first_frame = kNoFrame;
-        r.vx = r.vy = r.vz = 0.f;
+        r.pad = 0;
         int32_t x = 0, y = 0, z = 0;
         if (want) {
             r = in[j];
-            key_coords(g, r.key, x, y, z);
-            want = x <= g.dim[0] && y <= g.dim[1] && z <= g.dim[2];  // storage extent is dim+1 (grid.hpp:626)
+            if (r.key & kEpochFrame) {  // a frame's viewpoint (the same value from every exporter)
+                const uint32_t fid = (uint32_t)r.key;
+                if (fid < t.max_frames) {
+                    if (r.key & kEpochFrameHalf) {
+                        t.frame_vp[3 * (uint64_t)fid + 2] = r.a;
+                    } else {
+                        t.frame_vp[3 * (uint64_t)fid] = r.a;
+                        t.frame_vp[3 * (uint64_t)fid + 1] = r.b;
+                    }
+                }
+                want = false;
+            } else {
+                key_coords(g, r.key, x, y, z);
+                want = x <= g.dim[0] && y <= g.dim[1] && z <= g.dim[2];  // storage extent is dim+1 (grid.hpp:626)
+            }
         }
         const uint32_t bidx = want ? brick_index(g, x, y, z) : 0u;
         const uint32_t b = brick_acquire_wave(t, bidx, want);
@@ -2116,13 +2161,8 @@ __global__ __launch_bounds__(256) void k_epoch_import(const GridParams g, const 
         if (want) {
             const unsigned long long bit = 1ull << (((y & 7) << 3) | (z & 7));
             const unsigned long long old = atomicOr(reinterpret_cast<unsigned long long*>(&t.occ_mask[(uint64_t)b * 8 + (x & 7)]), bit);
-            if (!(old & bit)) f_first |= 1u << tt;  // (joins occ_list: the clean pass this import opens files its pre-dependant, k_materialize_new)
-            if (r.first_frame < t.max_frames) {
-                atomicMin(&t.first_frame[slot], r.first_frame);
-                t.frame_vp[3 * (uint64_t)r.first_frame] = r.vx;  // same value from every exporter
-                t.frame_vp[3 * (uint64_t)r.first_frame + 1] = r.vy;
-                t.frame_vp[3 * (uint64_t)r.first_frame + 2] = r.vz;
-            }
+            if (!(old & bit)) f_first |= 1u << tt;  // (joins occ_list: the clean pass this import opens files its pre-dependant, k_clean_begin)
+            if (r.first_frame < t.max_frames) atomicMin(&t.first_frame[slot], r.first_frame);
         }
     }
     __shared__ BlockReserveScratch brs;

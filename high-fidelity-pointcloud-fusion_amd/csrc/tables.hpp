@@ -75,6 +75,7 @@ enum Ctr : int {
     C_TOUCHED_SINGLE, // host mirror only (sum of word 4 of the striped lines): touched cells of the running pass in single-run bricks
     C_TABLE_MISS,   // work items of k_update_cells that found no slot in the LDS record table (they update HBM directly)
     C_OVF,          // entries in the overflow list of the running integrate launch (k_integrate -> k_integrate_overflow)
+    C_FRAMES,       // entries in frame_list (frames this handle has integrated, in any order)
     C_UPD_ROUNDS,   // sort rounds beyond the first that bricks of k_update_cells took (diagnostic: which bricks exceed one LDS round)
     C_COUNT = 32
 };
@@ -142,6 +143,7 @@ struct Tables {
     uint32_t* run_cnt;
     uint64_t* cand_key;    // clean scratch (unsorted / sorted ping-pong handled by the host)
     float* frame_vp;       // 3 per frame id
+    uint32_t* frame_list;  // ids of the frames this handle has integrated (C_FRAMES entries): the epoch exchange sends their viewpoints
     unsigned long long* ctr;
     // brick bins of the two-pass dependant update (kernels.hpp, k_integrate<BIN> + k_update)
     float4* bin_pt;       // (x, y, z, bits of the cell's index inside the brick) of points parked for k_update, grouped per brick

@@ -343,7 +343,7 @@ class OccupancyGrid:
         self._transport = transport
 
     def epoch_export(self):
-        """-> (device pointer, n_records) of the 32-byte records of cells occupied since the last exchange."""
+        """-> (device pointer, n_records) of the 16-byte records of the cells occupied and the frames integrated since the last exchange."""
         p = C.c_void_p()
         n = C.c_uint64()
         self._chk(lib().hfpf_epoch_export(self._h, C.byref(p), C.byref(n)))

@@ -8,7 +8,7 @@ boxes) and as a fallback when communicator creation fails.  This module holds ho
 """
 import numpy as np
 
-EPOCH_REC_BYTES = 32
+EPOCH_REC_BYTES = 16  # one record per newly occupied cell (key, first frame id), two per frame integrated since the last exchange (its viewpoint)
 
 
 def shard_frame_ids(n_local, rank, world, start=0):

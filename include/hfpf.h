@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HFPF_ABI_VERSION 5
+#define HFPF_ABI_VERSION 6
 
 /* hfpf_config.flags */
 #define HFPF_FLAG_FUSE_COLOR 1u /* EXTENSION: also average the member points' RGB per voxel (reference: never, grid.hpp:471-479) */
@@ -242,7 +242,9 @@ int hfpf_dist_info(hfpf_handle* h, int32_t* rank, int32_t* world);
 /* Drop the communicator again (e.g. when not every rank managed to create one); clean/extract become local calls. */
 int hfpf_dist_disable(hfpf_handle* h);
 /* Transport 2: bring your own.  The same exchange as explicit steps on device buffers (also how tests run several
- * virtual ranks on one GPU): export -> move the 32-byte records -> import into every other rank -> hfpf_clean;
+ * virtual ranks on one GPU): export -> move the 16-byte records (ABI 6; 32 bytes until ABI 5: one record per newly occupied cell --
+ * key, smallest frame id -- and two per frame integrated since the last exchange -- its viewpoint, which used to ride on every
+ * cell record) -> import into every other rank -> hfpf_clean;
  * at the end add the ranks' hfpf_stats_export words and hand the totals to hfpf_extract_with_stats.
  * Exported pointers are device memory owned by the handle, valid until its next mutating call. */
 int hfpf_epoch_export(hfpf_handle* h, const void** dev_records, uint64_t* n_records);

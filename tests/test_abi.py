@@ -19,7 +19,7 @@ def test_every_declared_symbol_is_exported(hfpf_mod):
     for n in names:
         assert hasattr(L, n), "libhfpf.so does not export %s" % n
     assert sorted(names) == sorted(hfpf_mod.EXPORTS), "python binding EXPORTS out of date with the headers"
-    assert L.hfpf_abi_version() == 5
+    assert L.hfpf_abi_version() == 6
     import hfpf_node
     NL = hfpf_node.lib()
     node_names = [n for n in _declared("hfpf_node.h") if n.startswith("hfpf_node_")]

@@ -32,7 +32,7 @@ def _free_port():
 class FakeGrid:
     """numpy stand-in for the transport-free entry points of the C ABI (hfpf_epoch_export / hfpf_epoch_import /
     hfpf_stats_export / hfpf_extract_with_stats / device_*), so HostStagedTransport runs on CPU under gloo."""
-    REC = np.dtype([("key", "<u8"), ("first_frame", "<u4"), ("vx", "<f4"), ("vy", "<f4"), ("vz", "<f4"), ("pad", "<u4", (2,))])
+    REC = np.dtype([("key", "<u8"), ("first_frame", "<u4"), ("pad", "<u4")])  # = hfpf_dist.EPOCH_REC_BYTES
 
     def __init__(self):
         self.cells = {}       # key -> first_frame (replicated after exchange)
@@ -65,7 +65,7 @@ class FakeGrid:
         return self._put(rec), len(rec)
 
     def epoch_import(self, dev, n):
-        rec = self.mem[dev][: n * 32].view(self.REC)
+        rec = self.mem[dev][: n * self.REC.itemsize].view(self.REC)
         for r in rec:
             k, f = int(r["key"]), int(r["first_frame"])
             self.cells[k] = min(self.cells.get(k, f), f)

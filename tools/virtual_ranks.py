@@ -105,7 +105,7 @@ def main():
     print("`python3 tools/virtual_ranks.py --epochs %d --frames %d` -- BASELINE configs[3] cameras (640x480, one per rank, distinct frame and pose seeds),"
           " shared 2 m^3 box @ 1 mm, epochs of %d frames per camera; every rank imports the other ranks' newly occupied cells and runs the clean pass"
           " for the union.  `clean ms` = HIP events around one rank's pass on its own stream (HFPF_CLEAN_NOWAIT=0, ranks one after the other);"
-          " `exchange` = 32-byte records a rank receives in the all-gather; `all-reduce` = (records + 1) x 64 B, what an extract at that point would reduce.\n" % (
+          " `exchange` = 16-byte records a rank receives in the all-gather (32-byte until ABI 5); `all-reduce` = (records + 1) x 64 B, what an extract at that point would reduce.\n" % (
               a.epochs, a.frames, a.frames))
     print("| ranks | pass | clean ms per rank (mean / max) | vs 1 rank | records received per rank | exchange MB per rank | import ms | normal records | statistics all-reduce MB | bricks |")
     print("|---|---|---|---|---|---|---|---|---|---|")
@@ -113,7 +113,7 @@ def main():
         b = base.get(r["epoch"])
         rel = "%.2fx" % (r["clean_ms_mean"] / b["clean_ms_mean"]) if b and b["clean_ms_mean"] > 0 else "-"
         print("| %d | %d | %.3f / %.3f | %s | %.0f | %.2f | %.3f | %d | %.1f | %d |" % (
-            r["world"], r["epoch"] + 1, r["clean_ms_mean"], r["clean_ms_max"], rel, r["recv_mean"], r["recv_mean"] * 32 / 1e6, r["import_ms_per_rank"],
+            r["world"], r["epoch"] + 1, r["clean_ms_mean"], r["clean_ms_max"], rel, r["recv_mean"], r["recv_mean"] * hfpf_dist.EPOCH_REC_BYTES / 1e6, r["import_ms_per_rank"],
             r["normals"], (r["normals"] + 1) * 64 / 1e6, r["bricks"]))
 
 
