@@ -165,7 +165,10 @@ class StagePool {
 
 constexpr int kStageSlots = 8;
 constexpr size_t kXferChunk = 16u << 20;  // bytes per pinned chunk of extract's row download
-constexpr int kProbeFrames = 8;  // frames of a plan-less batch that go ahead of the rest to measure the per-brick demand
+#ifndef HFPF_PROBE_FRAMES
+#define HFPF_PROBE_FRAMES 8
+#endif
+constexpr int kProbeFrames = HFPF_PROBE_FRAMES;  // frames of a plan-less batch that go ahead of the rest to measure the per-brick demand
 constexpr int kFrameSlots = 8;  // uploads run ahead of the kernels by up to this many frames
 
 }  // namespace
