@@ -672,8 +672,13 @@ int alloc_tables(hfpf_handle* h)
 
 // (rocPRIM sorts fewer than a million keys by block sort + log2(n / 1024) merge launches -- nine launches, 57 us, for the 74 K candidate
 // keys of a steady clean pass.  Forcing its radix path for small inputs, radix_sort_config<..., 8192>, was measured in round 4: a
-// histogram, a scan and per 8-bit digit two buffer fills and one sweep, fifteen launches and ~100 us for the same keys.  Default kept.)
-using sort_config = rocprim::default_config;
+// histogram, a scan and per 8-bit digit two buffer fills and one sweep, fifteen launches and ~100 us for the same keys: the merge path stays.)
+// What does help: blocks of 4,096 sorted keys instead of 1,024 -- two merge launches less for those 74 K keys (clean passes 3.66 -> 3.57 ms
+// per 1000-frame run; 8,192-key blocks: 3.64).
+#ifndef HFPF_SORT_BLOCK_ITEMS
+#define HFPF_SORT_BLOCK_ITEMS 4
+#endif
+using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 1024, HFPF_SORT_BLOCK_ITEMS>, rocprim::default_config>;
 
 // Cell keys: only the low GridParams::key_bits bits are significant (an all-ones sentinel still sorts behind every valid key:
 // a valid cell has x < dim <= 2^bits_x - 1, so its key is never all ones).
@@ -1303,8 +1308,9 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     const bool reg_small = n_in < (1ull << 18);  // tiles per workgroup: kernels.hpp k_register
     const uint64_t reg_tile = 256ull * (reg_small ? kRegTilesSmall : kRegTilesLarge);  // step-major, whole workgroups per step
     const uint64_t reg_blocks = ((n_in + reg_tile - 1) / reg_tile) * (2ull * (uint64_t)h->g.K + 1ull);
-    if (reg_small) hipLaunchKernelGGL(k_register<kRegTilesSmall>, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals);
-    else hipLaunchKernelGGL(k_register<kRegTilesLarge>, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals);
+    const uint32_t count_deps = full ? 0u : 1u;  // (the compacting rebuild counts for itself, from zero)
+    if (reg_small) hipLaunchKernelGGL(k_register<kRegTilesSmall>, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals, count_deps);
+    else hipLaunchKernelGGL(k_register<kRegTilesLarge>, dim3((unsigned)std::max<uint64_t>(reg_blocks, 1)), dim3(256), 0, s, h->g, t, kCountOnDevice, n_normals, count_deps);
     HIPCHK(h, hipGetLastError());
     uint64_t n_reg = 0, n_pre = 0, inc_touched = 0;
     // registrations already present in dep[]: every pass files all of its own, so that is the counter as this pass found it
@@ -1315,8 +1321,6 @@ int clean_locked(hfpf_handle* h, int pre_rc)
     // cannot run out of dep[] half-way (the one overflow the host would have to repair by compacting).
     const bool no_wait = !full && reg_ub < (1ull << 21) && h->clean_small_nowait;
     if (!full) {
-        const unsigned count_blocks = blocks_for(reg_ub, 256 * kListTiles);
-        hipLaunchKernelGGL(k_depinc_count, dim3(count_blocks), dim3(256), 0, s, t, reg_first, kCountOnDevice);
         hipLaunchKernelGGL(k_depinc_offsets, dim3(blocks_for(reg_ub, 256 * kListTiles)), dim3(256), 0, s, t, kCountOnDevice);
         hipLaunchKernelGGL(k_depinc_fill, dim3(blocks_for(reg_ub, 256)), dim3(256), 0, s, t, reg_first, kCountOnDevice);
         HIPCHK(h, hipGetLastError());

@@ -1570,8 +1570,11 @@ __global__ __launch_bounds__(128) void k_normal(const GridParams g, const Tables
 // independent; "last registrant wins" on unoccupied cells (grid.hpp:443-449) is an atomicMax over record ids -- they ascend from
 // pass to pass -- with the contests inside a pass settled by the canonical (x, y, z) key (see below: ids follow the Z-order there).
 template <int kRegTiles>
-__global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand_arg, const uint64_t base)
+__global__ __launch_bounds__(256) void k_register(const GridParams g, const Tables t, const uint64_t n_cand_arg, const uint64_t base, const uint32_t count_deps)
 {
+    // count_deps: the incremental dependant-table update follows (no compacting rebuild was decided): a registration on an occupied
+    // cell is counted into the cell's scratch word right here, and the first one of a cell files the cell in touched_list -- what a
+    // separate pass over reg_occ (k_depinc_count) did until round 4, one launch and one re-read of the list earlier.
     const uint64_t n_cand = n_cand_arg == kCountOnDevice ? cand_count(t, base) : n_cand_arg;  // the same in every thread
     if (n_cand == 0) return;
     // Step-major mapping: a wave holds 64 key-adjacent voxels at the SAME step, so its targets sit in the same few bricks.
@@ -1586,7 +1589,7 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
     const uint32_t step_idx = (uint32_t)(blk_first / per_step);
     const int i = (int)step_idx - g.K;
     uint32_t slot_[kRegTiles], nid_[kRegTiles];
-    uint32_t f_occ = 0;
+    uint32_t f_occ = 0, f_fresh = 0;
 #pragma unroll
     for (int tt = 0; tt < kRegTiles; tt++) {
         const uint64_t r = blk_first % per_step + (uint64_t)tt * 256u + threadIdx.x;
@@ -1611,7 +1614,10 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         const bool occ = want && (t.occ_mask[o_plane] & o_bit);
         slot_[tt] = slot;
         nid_[tt] = (uint32_t)nid;
-        if (occ) f_occ |= 1u << tt;
+        if (occ) {
+            f_occ |= 1u << tt;
+            if (count_deps && atomicAdd(&t.dep_tmp[slot], 1u) == 0u) f_fresh |= 1u << tt;  // (scratch words are zero between passes)
+        }
         if (want && !occ) {
             // An unoccupied target keeps ONE dependant, in pre_dep[slot] and nowhere else until the cell is occupied (k_materialize_new).
             const uint32_t old = atomicMax(&t.pre_dep[slot], (uint32_t)nid);
@@ -1654,6 +1660,14 @@ __global__ __launch_bounds__(256) void k_register(const GridParams g, const Tabl
         }
     }
     if (overflow) atomicOr(&t.ctr[C_ERR], (unsigned long long)E_REG);
+    if (count_deps) {  // (wave-uniform) the cells this workgroup was the first to count a registration for
+#pragma unroll
+        for (int tt = 0; tt < kRegTiles; tt++) n_occ[tt] = (f_fresh >> tt) & 1u;
+        block_reserve_tiles<kRegTiles>(&t.ctr[C_TOUCHED], n_occ, ri, trs);  // capacity max_touched = max_reg >= the registrations of any pass
+#pragma unroll
+        for (int tt = 0; tt < kRegTiles; tt++)
+            if (n_occ[tt]) t.touched_list[ri[tt]] = slot_[tt];
+    }
 }
 
 // K5b: buffer replay (grid.hpp:418-440), cell-centric.  The reference replays a cell's buffer once per voxel that
@@ -1856,36 +1870,11 @@ __global__ __launch_bounds__(256) void k_dep_reset(const Tables t, const uint64_
 
 
 // ---- incremental dependant-table update ---------------------------------------------------------------
-// A clean pass only appends registrations (occupied targets) or replaces the single entry of an
-// unoccupied target, so only the cells touched by THIS pass are rewritten: their old list is copied to
-// fresh space at the end of dep[] and the new entries appended.  The space of the old list is garbage
-// until the next full rebuild (k_dep_count / k_dep_offsets / k_dep_fill), which the host runs when dep[]
-// fills up.
-
-__device__ __forceinline__ void depinc_count_body(const Tables& t, const uint64_t reg_first, const uint64_t n_reg_arg, const uint32_t block)
-{
-    const uint64_t n_reg = n_reg_arg == kCountOnDevice ? min((uint64_t)t.ctr[C_REG], t.max_reg) : n_reg_arg;
-    uint32_t slot_[kListTiles];
-    uint32_t f_fresh = 0;
-#pragma unroll
-    for (int tt = 0; tt < kListTiles; tt++) {
-        const uint64_t j = reg_first + ((uint64_t)block * kListTiles + tt) * 256u + threadIdx.x;
-        slot_[tt] = 0;
-        if (j < n_reg) {
-            slot_[tt] = t.reg_occ[j].x;
-            if (atomicAdd(&t.dep_tmp[slot_[tt]], 1u) == 0u) f_fresh |= 1u << tt;
-        }
-    }
-    __shared__ TileReserveScratch<kListTiles> trs;
-    uint32_t n_f[kListTiles];
-    unsigned long long ti[kListTiles];
-#pragma unroll
-    for (int tt = 0; tt < kListTiles; tt++) n_f[tt] = (f_fresh >> tt) & 1u;
-    block_reserve_tiles<kListTiles>(&t.ctr[C_TOUCHED], n_f, ti, trs);  // tile-major: neighbouring registrations stay neighbours
-#pragma unroll
-    for (int tt = 0; tt < kListTiles; tt++)
-        if (n_f[tt]) t.touched_list[ti[tt]] = slot_[tt];
-}
+// A clean pass only appends registrations to the lists of occupied cells, so only the cells touched by THIS pass are looked at
+// (k_register counts the pass's registrations per cell and files the touched cells): k_depinc_offsets extends a list in place while it
+// fits the power-of-two block it owns (dep_capacity) and otherwise copies it into a fresh block at the end of dep[], k_depinc_fill
+// writes the new entries.  The space of a relocated list is garbage until the next full rebuild (k_dep_count / k_dep_offsets /
+// k_dep_fill), which the host runs when dep[] fills up.
 
 __global__ __launch_bounds__(256) void k_depinc_offsets(const Tables t, const uint64_t n_touched_arg)
 {
@@ -1961,7 +1950,6 @@ __global__ __launch_bounds__(256) void k_depinc_fill(const Tables t, const uint6
     if (k + 1 == (uint32_t)((info >> kDepCntShift) & kDepCntMask)) t.dep_tmp[r.x] = kTouchedMark | ((v >> 16) & kDepOldMax);
 }
 
-__global__ __launch_bounds__(256) void k_depinc_count(const Tables t, const uint64_t reg_first, const uint64_t n_reg_arg) { depinc_count_body(t, reg_first, n_reg_arg, blockIdx.x); }
 
 // ---- K6 extract -----------------------------------------------------------------------------------
 // Keys of the records that downloadData would emit: x<xdim && y<ydim && z<zdim (grid.hpp:463-465);

@@ -17,7 +17,7 @@ f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
 out = []
 for r in csv.DictReader(open(f)):
     n = r["Name"]
-    for k in ("k_integrate_overflow", "k_integrate<", "k_update", "k_replay", "k_register", "k_buffer", "k_normal", "k_depinc_count", "k_depinc_offsets", "k_depinc_fill", "k_clean_begin", "k_gate"):
+    for k in ("k_integrate_overflow", "k_integrate<", "k_update", "k_replay", "k_register", "k_buffer", "k_normal", "k_depinc_offsets", "k_depinc_fill", "k_clean_begin", "k_gate"):
         if k in n:
             k = k.rstrip("<")
             out.append("%s %.1f us x%s" % (k, float(r["AverageNs"]) / 1e3, r["Calls"]))
