@@ -231,9 +231,9 @@ def main():
             pinned[f * frame_bytes:(f + 1) * frame_bytes] = buf
     log("rank %d: staged %d frames (%.2f GB) in %.1f s" % (rank, n_gen, n_gen * frame_bytes / 1e9, time.perf_counter() - t_gen))
 
-    def run_stream(nf):
-        """nf frames: one integrate call per clean epoch (or --frames-per-call), clean after every epoch, final clean."""
-        done = 0
+    def run_stream(nf, start=0, final_clean=True):
+        """frames [start, nf): one integrate call per clean epoch (or --frames-per-call), clean after every epoch, final clean."""
+        done = start
         while done < nf:
             nxt = nf
             if clean_every:
@@ -244,7 +244,8 @@ def main():
             done += b
             if clean_every and done % clean_every == 0 and done < nf:
                 grid.clean()  # synchronises (reads device counters)
-        grid.clean()
+        if final_clean:
+            grid.clean()
 
     # ---- warmup (untimed) ----
     if Wm > 0:
@@ -283,10 +284,22 @@ def main():
     if True:  # every rank: the clean passes inside are collectives
         grid.clear()
         grid.sync()
+        names = (("k_integrate", 2), ("k_update_cells", 3), ("k_buffer", 4))
+        first = min(clean_every, n_frames) if clean_every else n_frames
         grid.kernel_timing(2)
-        run_stream(n_frames)
+        run_stream(first, final_clean=False)  # the first epoch (everything is buffered, no dependant exists yet) ...
+        if first < n_frames:
+            grid.clean()
         grid.sync()
-        per_kernel = {name: grid.kernel_time(kid) for name, kid in (("k_integrate", 2), ("k_update_cells", 3), ("k_buffer", 4))}
+        pk_first = {name: grid.kernel_time(kid) for name, kid in names}
+        grid.kernel_timing(2)  # (restarts the accumulators)
+        if first < n_frames:
+            run_stream(n_frames, start=first)  # ... and the steady state behind the first clean pass, apart
+        else:
+            grid.clean()
+        grid.sync()
+        per_kernel_steady = {name: grid.kernel_time(kid) for name, kid in names}
+        per_kernel = {name: (pk_first[name][0] + per_kernel_steady[name][0], pk_first[name][1] + per_kernel_steady[name][1]) for name, _ in names}
         grid.kernel_timing(False)
 
     # ---- extract (timed separately) ----
@@ -388,6 +401,8 @@ def main():
                         k["traffic_bytes_steady_call"] = round(tb)
                         k["traffic_GBps"] = round(tb / avg_s / 1e9, 2)
                         k["traffic_frac"] = round(tb / avg_s / 1e9 / HBM_PEAK_GBPS, 5)
+                if per_kernel_steady[name][1]:
+                    k["steady_avg_ms_per_call"] = round(per_kernel_steady[name][0] / per_kernel_steady[name][1], 5)  # calls behind the first clean pass
                 kernels[name] = k
             upd_s = per_kernel["k_update_cells"][0] / 1e3
             kernels["pairs_per_call"] = round(ctr["dep_pairs_tested"] / max(per_kernel["k_update_cells"][1], 1))
@@ -400,10 +415,12 @@ def main():
             sq = pmc["sq"]["k_update"]
             pairs = pmc["sq"].get("pairs_per_launch") or 0
             if pairs and sq.get("SQ_INSTS_VALU"):
-                lanes = sq.get("active_lane_fraction") or 1.0
-                li = sq["SQ_INSTS_VALU"] * 64.0 * lanes / pairs
+                lanes = sq.get("active_lane_fraction")  # None: the passes of this workload did not collect SQ_THREAD_CYCLES_VALU (all 64 lanes counted)
+                li = sq["SQ_INSTS_VALU"] * 64.0 * (lanes or 1.0) / pairs
                 compute = {"bound": "valu (k_update_cells)", "unit": "VALU lane-instructions per (point, dependant) pair", "achieved": round(li, 1),
-                           "minimum": 48, "frac": round(48.0 / li, 4), "active_lane_fraction": round(lanes, 3),
+                           "minimum": 48, "frac": round(48.0 / li, 4), "active_lane_fraction": round(lanes, 3) if lanes else None,
+                           # the same ceiling as a time: what the kernel's VALU wave-instructions alone need to issue against its measured steady time
+                           "valu_issue_floor_ms": round(sq["SQ_INSTS_VALU"] * 4.0 / (SIMDS * CLOCK_HZ) * 1e3, 4),
                            "lds_bank_conflict_share": round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 4) if sq.get("SQ_LDS_IDX_ACTIVE") else None}
         # ... and of k_integrate: the time its VALU wave-instructions alone need to issue (4 cycles each on one of 1024 SIMDs) against
         # the kernel's measured time per steady call
@@ -411,12 +428,13 @@ def main():
         if pmc is not None and pmc.get("sq", {}).get("k_integrate", {}).get("SQ_INSTS_VALU") and per_kernel is not None and per_kernel["k_integrate"][1]:
             sqi = pmc["sq"]["k_integrate"]
             floor_ms = sqi["SQ_INSTS_VALU"] * 4.0 / (SIMDS * CLOCK_HZ) * 1e3
-            meas_ms = per_kernel["k_integrate"][0] / per_kernel["k_integrate"][1]
+            st = per_kernel_steady["k_integrate"]
+            meas_ms = st[0] / st[1] if st[1] else per_kernel["k_integrate"][0] / per_kernel["k_integrate"][1]
             compute_integrate = {"bound": "valu issue (k_integrate)", "unit": "ms per steady integrate launch", "valu_issue_floor_ms": round(floor_ms, 4),
                                  "measured_ms": round(meas_ms, 4), "frac": round(floor_ms / meas_ms, 4) if meas_ms > 0 else None,
                                  "valu_wave_instructions": round(sqi["SQ_INSTS_VALU"]), "salu_wave_instructions": round(sqi.get("SQ_INSTS_SALU", 0)),
                                  "active_lane_fraction": round(sqi["active_lane_fraction"], 3) if sqi.get("active_lane_fraction") else None,
-                                 "note": "measured_ms averages every k_integrate launch of a pass incl. the first epoch's; the counters are means over the steady launches"}
+                                 "note": "measured_ms = HIP events around k_integrate + k_integrate_overflow of the calls behind the first clean pass (the steady state the counters are means over)"}
         if ctr["dep_pairs_tested"] == 0:
             warnings.append("dep_pairs_tested == 0: the stream never reached the steady state (no dependant updates ran); not the headline configuration")
         out = {
