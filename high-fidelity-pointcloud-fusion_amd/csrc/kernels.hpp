@@ -284,9 +284,6 @@ __device__ __forceinline__ const Tables& kernarg_tables()
 #ifndef HFPF_INT_WAVES_BIN
 #define HFPF_INT_WAVES_BIN 7
 #endif
-#ifndef HFPF_INT_REGION_LOADS_BY_ALL
-#define HFPF_INT_REGION_LOADS_BY_ALL 0
-#endif
 template <bool PACKED16, bool COLOR, bool BIN>
 __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) void k_integrate(const IntegrateArgs A, const uint8_t* __restrict__ frames,
                                                    const uint64_t frame_stride, const uint32_t n_pts, const uint32_t n_frames,
@@ -479,22 +476,14 @@ __global__ __launch_bounds__(256, BIN ? HFPF_INT_WAVES_BIN : HFPF_INT_WAVES) voi
             // phase 2: every group leader reserves for its group in ONE wave-instruction (one memory round trip per tile);
             // the counter also records the demand the next launch's plan is made from
             uint32_t base = 0, cap = 0, roff = 0;
-            if (want_bin && grp_leader == lane) base = atomicAdd(&t.bin_fill[rg], grp_size);
-#if HFPF_INT_REGION_LOADS_BY_ALL
-            if (want_bin) {  // the region's capacity and first entry, read by every lane of the group (one address: one request) instead of
-                cap = t.bin_capb[rg];  // by its leader and handed round through two more cross-lane reads
-                roff = t.bin_off[rg];
-            }
-            base = __shfl(base, (int)grp_leader);
-#else
             if (want_bin && grp_leader == lane) {
+                base = atomicAdd(&t.bin_fill[rg], grp_size);
                 cap = t.bin_capb[rg];
                 roff = t.bin_off[rg];
             }
             base = __shfl(base, (int)grp_leader);
             cap = __shfl(cap, (int)grp_leader);
             roff = __shfl(roff, (int)grp_leader);
-#endif
             if (todo && !probe) {
                 const uint32_t pos = base + grp_rank;
                 if (pos < cap) {
@@ -1086,9 +1075,6 @@ __global__ __launch_bounds__(THREADS, WAVES) void k_update_cells(const GridParam
             c_tested += cur.p_hi - cur.p_lo;
             c_member += (uint32_t)a_n;
             if (a_n == 0) continue;
-#ifdef HFPF_TIMING_ONLY_SKIP_DUP_INSERT  // timing-only build (results wrong on purpose): only the first chunk of a (cell, entry) touches the record table --
-            if (cur.p_lo != 0) continue;  // the most a reduction over the lanes of one record could save, before it costs anything itself
-#endif
             const uint32_t sid = __float_as_uint(cur.e0.x);
             uint32_t h = upd2_hash(sid);
             bool placed = false;
