@@ -95,6 +95,7 @@ def _worker(rank, world, port, q):
     try:
         import torch.distributed as dist
         import hfpf_dist
+        assert FakeGrid.REC.itemsize == hfpf_dist.EPOCH_REC_BYTES  # the stand-in's records are the transports' records
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
