@@ -198,6 +198,7 @@ struct hfpf_handle {
     int integrate_grid = 1536;
     int upd_shape_forced = -1;  // HFPF_UPD_SHAPE
     bool upd_wide = false;      // the 352-slot record table overflowed in this session: k_update_cells takes the 512-slot shape
+    bool trace_shape = false;   // HFPF_TRACE_SHAPE=1: one stderr line per pick_update_shape() window
     unsigned long long upd_miss_seen = 0, upd_member_seen = 0;
     uint32_t launch_seq = 0;  // integrate launches so far (rotates the log append regions)
     uint64_t frames_integrated = 0;
@@ -747,12 +748,19 @@ int acquire_stage(hfpf_handle* h, uint32_t n_frames, StageSlot** out)
 // Which instantiation of k_update_cells a launch takes (kernels.hpp, UpdShape): 0 dense, 1 wide table.  HFPF_UPD_SHAPE=0|1 forces
 // one.  Otherwise the dense shape, until the items that found no slot in its table exceed one in 500 member pairs (counted by the
 // kernel, seen by the host at its counter read-backs -- every clean pass); then the wide table for the rest of the session.
+// The streaming replay of a clean pass is the same kernel with the same table and counts its misses into the same word, so its
+// members belong in the denominator too: a caller that reads the counters between a clean pass and the next integrate call
+// (hfpf_get_counters, hfpf_get_kernel_time) makes a window that holds the replay alone -- a few hundred misses against no update
+// member at all, which used to switch the session to the wide shape (bench.py's per-kernel pass did exactly that).
 int pick_update_shape(hfpf_handle* h, double points, uint32_t nb)
 {
     (void)points;
     (void)nb;
     if (h->upd_shape_forced >= 0) return h->upd_shape_forced;
-    const unsigned long long miss = h->h_ctr[C_TABLE_MISS], member = h->h_ctr[C_DEP_MEMBER];
+    const unsigned long long miss = h->h_ctr[C_TABLE_MISS], member = h->h_ctr[C_DEP_MEMBER] + h->h_ctr[C_REPLAY_MEMBER];
+    if (h->trace_shape)
+        fprintf(stderr, "hfpf: update shape window: %llu table misses, %llu members (%llu of them replayed so far), %s\n", miss - std::min(miss, h->upd_miss_seen),
+                member - std::min(member, h->upd_member_seen), h->h_ctr[C_REPLAY_MEMBER], h->upd_wide ? "wide" : "dense");
     if (!h->upd_wide && miss > h->upd_miss_seen && (miss - h->upd_miss_seen) * 500ull > member - std::min(member, h->upd_member_seen)) h->upd_wide = true;
     h->upd_miss_seen = miss;
     h->upd_member_seen = member;
@@ -1484,6 +1492,7 @@ int hfpf_create(const hfpf_config* cfg, hfpf_handle** out)
         h->update_cells = !(uf && uf[0] == 'p');
         if (const char* hb = getenv("HFPF_HOST_BATCH")) h->host_batch = std::max(1, std::min(atoi(hb), kFrameSlots));
         if (const char* us = getenv("HFPF_UPD_SHAPE")) h->upd_shape_forced = std::max(0, std::min(atoi(us), 1));
+        if (const char* tr = getenv("HFPF_TRACE_SHAPE")) h->trace_shape = tr[0] != '0';
         if (const char* sp = getenv("HFPF_BIN_SPARE")) h->bin_spare = sp[0] != '0';
         if (const char* sr = getenv("HFPF_STREAM_REPLAY")) h->stream_replay = sr[0] != '0';
         if (const char* bs = getenv("HFPF_BIN_SLACK")) h->bin_slack = std::max(1.0f, std::min(4.0f, (float)atof(bs)));
