@@ -818,13 +818,17 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
     const bool bin = h->binned;
     const uint32_t pre_possible = (h->h_ctr[C_NORMALS] > 0 || h->normals_possible) ? 1u : 0u;  // a clean pass has run: unoccupied cells may carry a dependant
     uint32_t launch_frames = n_frames, probe = 0;
-    if (bin && !h->bin_have_hist && n_frames > (uint32_t)kProbeFrames) {
+    // frames of the dry run: twice as many for a long batch.  For 150 frames of 640x480 with random poses the first 8 find 46 % of
+    // the bricks the batch touches and 16 find 50 % (32: 57 %), and the plan made from the larger sample sends 30 % fewer points
+    // through the overflow list (268 K instead of 382 K per 1000-frame pass): whole job +1.5 %; 32 frames add nothing.
+    const uint32_t probe_frames = n_frames >= 8u * (uint32_t)kProbeFrames ? 2u * (uint32_t)kProbeFrames : (uint32_t)kProbeFrames;
+    if (bin && !h->bin_have_hist && n_frames > probe_frames) {
         // No plan for the per-brick bins yet (first batch of a session): a dry run of the batch's first frames claims their
         // bricks and records the per-region demand, so that the real launch below parks from its first point.  One extra
         // read-back (the brick count), once per session; batches of up to kProbeFrames frames just take the direct forms.
         HIPCHK(h, hipMemsetAsync(h->t.bin_fill, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
         HIPCHK(h, hipMemsetAsync(h->t.bin_capb, 0, 2 * (h->t.max_bricks + 2) * 4, h->stream));
-        launch_frames = kProbeFrames;
+        launch_frames = probe_frames;
         probe = 1;
         const uint32_t log_rot = 0;
         const dim3 pgrid((unsigned)std::min<uint64_t>((uint64_t)blocks_for(n_points, 256) * launch_frames, (uint64_t)h->integrate_grid));
@@ -842,7 +846,7 @@ int integrate_device_locked(hfpf_handle* h, const void* dev_base, uint32_t n_fra
         if (rcp) return rcp;
         h->bin_have_hist = true;
         h->bin_from_probe = true;  // the plan of the launch below comes from a sample: more slack per region
-        h->bin_prev_points = (double)n_points * kProbeFrames;
+        h->bin_prev_points = (double)n_points * probe_frames;
         launch_frames = n_frames;
         probe = 0;
     }

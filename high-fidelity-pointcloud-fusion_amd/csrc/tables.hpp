@@ -290,6 +290,51 @@ __device__ inline uint32_t brick_acquire_single(const Tables& t, uint32_t bidx)
     return 0;
 }
 
+// The claims of one wave, side by side: `leader` lanes hold DISTINCT directory entries.  Three phases in program order, so that
+// every lane that won an entry has published its id before any lane of the wave starts to wait for another wave's:
+//   1. every leader reads its entry and tries the CAS 0 -> kLock
+//   2. the winners take their ids with ONE atomic on the brick counter for the wave (a claim used to take its own: the counter is
+//      one address for the whole chip, ~12 ns a hit, and a dry run or a session's first launch claims ~10,000 bricks -- more than
+//      a tenth of a millisecond of nothing but that counter) and publish them
+//   3. a leader that found its entry locked by another wave waits for the id (bounded).
+// Convergent: all 64 lanes call it; returns the id for leader lanes (0 on failure), 0 for the others.
+__device__ inline uint32_t brick_claim_leaders(const Tables& t, uint32_t bidx, bool leader)
+{
+    const uint32_t lane = lane_id();
+    uint32_t* p = &t.dir[leader ? bidx : 0u];
+    uint32_t v = 0;
+    bool won = false;
+    if (leader) {
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0) {
+            const uint32_t old = atomicCAS(p, 0u, kLock);
+            won = old == 0;
+            v = won ? kLock : old;
+        }
+    }
+    const unsigned long long wm = __ballot(won);
+    if (wm) {
+        const int first = __ffsll((long long)wm) - 1;
+        unsigned long long base = 0;
+        if (lane == (uint32_t)first) base = atomicAdd(&t.ctr[C_BRICKS], (unsigned long long)__popcll(wm));
+        base = __shfl(base, first);
+        if (won) {
+            const unsigned long long id = base + (unsigned long long)__popcll(wm & ((1ull << lane) - 1ull)) + 1ull;
+            if (id > t.max_bricks) {
+                atomicOr(&t.ctr[C_ERR], (unsigned long long)E_BRICKS);
+                __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = 0;
+            } else {
+                t.brick_lin[id] = bidx;
+                __hip_atomic_store(p, (uint32_t)id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                v = (uint32_t)id;
+            }
+        }
+    }
+    if (leader && v == kLock) v = brick_acquire_single(t, bidx);  // another wave holds the entry: its id is on its way
+    return leader ? v : 0u;
+}
+
 // Wave-level election: every lane that needs a brick which is not there yet takes part; one lane per
 // distinct directory entry runs the claim, the others receive its id through a shuffle.
 // Must be reached by all 64 lanes of the wave (convergent); `want` masks the lanes with real work.
@@ -315,7 +360,9 @@ __device__ inline uint32_t brick_acquire_wave(const Tables& t, uint32_t bidx, bo
     }
     const uint32_t leader_lane = need ? (uint32_t)(__ffsll((long long)grp) - 1) : lane;
     uint32_t id = v;
-    if (need && leader_lane == lane) id = brick_acquire_single(t, bidx);
+    const bool claims = need && leader_lane == lane;
+    const uint32_t claimed = brick_claim_leaders(t, bidx, claims);
+    if (claims) id = claimed;
     const uint32_t got = (uint32_t)__shfl((int)id, (int)leader_lane);
     return need ? got : v;
 }
@@ -338,7 +385,9 @@ __device__ inline uint32_t brick_acquire_groups(const Tables& t_in, uint32_t bid
     // the leader claims if ANY lane of its group still needs the brick
     const unsigned long long need_mask = __ballot(need);
     uint32_t id = v;
-    if (want && leader == lane && (need_mask & same_brick) != 0) id = brick_acquire_single(t, bidx);
+    const bool claims = want && leader == lane && (need_mask & same_brick) != 0;
+    const uint32_t claimed = brick_claim_leaders(t, bidx, claims);
+    if (claims) id = claimed;
     const uint32_t got = (uint32_t)__shfl((int)id, (int)leader);
     return (want && (need_mask & same_brick) != 0) ? got : v;
 }
