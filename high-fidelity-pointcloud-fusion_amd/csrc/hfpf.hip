@@ -555,20 +555,27 @@ int setup_params(hfpf_handle* h)
     return HFPF_OK;
 }
 
-int reset_state(hfpf_handle* h)
+// bricks_used / normals_used: how far the session got into the brick pool and the record table (hfpf_clear knows; everything at
+// create).  Per-cell and per-brick arrays are indexed by brick id, records by record id, and both are handed out in sequence, so a
+// reset only has to cover the prefix the session used: the bench's handle is sized for 300,000 bricks and uses 22,000 -- 7 GB of
+// resets become 0.6 GB.
+int reset_state(hfpf_handle* h, uint64_t bricks_used = ~0ull, uint64_t normals_used = ~0ull)
 {
     Tables& t = h->t;
     hipStream_t s = h->stream;
+    const uint64_t nb = std::min<uint64_t>(bricks_used, t.max_bricks);                     // ids 1..nb (+ the unused id 0)
+    const uint64_t nsl = std::min<uint64_t>(h->n_slots, (nb + 1) * (uint64_t)kBrickCells);  // their cells
+    const uint64_t nn = std::min<uint64_t>(normals_used, t.max_normals);
     HIPCHK(h, hipMemsetAsync(t.dir, 0, h->dir_entries * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.info, 0, h->n_slots * 8, s));
-    HIPCHK(h, hipMemsetAsync(t.first_frame, 0xFF, h->n_slots * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.buf_head, 0, h->n_slots * 4 * kChains, s));
-    HIPCHK(h, hipMemsetAsync(t.stat_id, 0, h->n_slots * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.pre_dep, 0, h->n_slots * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.dep_tmp, 0, h->n_slots * 4, s));
-    HIPCHK(h, hipMemsetAsync(t.occ_mask, 0, (t.max_bricks + 1) * 8 * 8, s));
-    HIPCHK(h, hipMemsetAsync(t.stats, 0, (t.max_normals + 1) * kStatWords * 8, s));
-    HIPCHK(h, hipMemsetAsync(t.nd_mask, 0, (t.max_bricks + 1) * 8 * 2 * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.info, 0, nsl * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.first_frame, 0xFF, nsl * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.buf_head, 0, nsl * 4 * kChains, s));
+    HIPCHK(h, hipMemsetAsync(t.stat_id, 0, nsl * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.pre_dep, 0, nsl * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.dep_tmp, 0, nsl * 4, s));
+    HIPCHK(h, hipMemsetAsync(t.occ_mask, 0, (nb + 1) * 8 * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.stats, 0, (nn + 1) * kStatWords * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.nd_mask, 0, (nb + 1) * 8 * 2 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.ctr, 0, C_COUNT * 8, s));
     HIPCHK(h, hipMemsetAsync(t.log_ctr, 0, kLogRegions * 16 * 8, s));
     HIPCHK(h, hipMemsetAsync(t.bin_fill, 0, 2 * (t.max_bricks + 2) * 4, s));
@@ -2258,7 +2265,13 @@ int hfpf_clear(hfpf_handle* h)
     std::lock_guard<std::mutex> lk(h->mtx);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->pend_n = 0;  // host frames still waiting for their launch would be wiped with the rest
-    int rc = reset_state(h);
+    // how far the session got (the counters as the device has them now); a handle whose stream has failed is reset in full
+    uint64_t bricks_used = ~0ull, normals_used = ~0ull;
+    if (read_counters(h) == HFPF_OK) {
+        bricks_used = h->h_ctr[C_BRICKS];
+        normals_used = h->h_ctr[C_NORMALS];
+    }
+    int rc = reset_state(h, bricks_used, normals_used);
     h->dirty = true;  // clearVoxels sets state_changed, grid.hpp:169
     return rc;
 }

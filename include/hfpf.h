@@ -208,7 +208,9 @@ int hfpf_write_pcd_xyzrgb(const hfpf_row* rows, uint64_t n_rows, const char* pat
 int hfpf_write_pcd_binary(const hfpf_row* rows, uint64_t n_rows, const char* path);
 
 /* OccupancyGrid::clearVoxels (grid.hpp:167-183; call site node.cpp:438).  Full reset (documented
- * deviation: the reference leaves stale keys and dependants-only blocks behind). */
+ * deviation: the reference leaves stale keys and dependants-only blocks behind).  Waits for the work enqueued on the handle
+ * (it reads how many bricks and records the session used and resets that much of the tables, not their whole capacity);
+ * frames of hfpf_integrate still waiting for their launch are dropped. */
 int hfpf_clear(hfpf_handle* h);
 
 /* Wait for all queued work of this handle; surfaces deferred capacity/HIP errors. */
