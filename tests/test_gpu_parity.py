@@ -129,6 +129,52 @@ def test_clear_then_rerun_is_identical(hfpf_mod, synth_mod):
     assert r1.tobytes() == r2.tobytes()  # integer sums: bitwise reproducible run to run
 
 
+def test_clear_after_a_larger_session_leaves_nothing_behind(hfpf_mod, synth_mod):
+    """hfpf_clear resets the part of the tables the session used (bricks and records are handed out in sequence), not their
+    capacity: a session that follows a LARGER one, and one that follows a SMALLER one and grows past its bricks, must both
+    give what a fresh handle gives."""
+    big = scenes.Scene(6, 160, 120, 0.001, fx=615.0, clean_every=3)
+    small = scenes.Scene(3, 160, 120, 0.001, fx=615.0, seed=0xBEEF, pose_seed=0x77, clean_every=2, max_angle=5.0)
+    fresh = {}
+    for name, sc in (("big", big), ("small", small)):
+        with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as g:
+            fresh[name] = scenes.run(g, sc, "integrate").tobytes()
+            assert len(fresh[name])
+    with hfpf_mod.OccupancyGrid(resolution=big.resolution, bbox=big.bbox, **SMALL) as g:
+        assert scenes.run(g, big, "integrate").tobytes() == fresh["big"]
+        used_big = g.counters()["bricks_allocated"]
+        g.clear()
+        assert scenes.run(g, small, "integrate").tobytes() == fresh["small"]  # after the larger session
+        used_small = g.counters()["bricks_allocated"]
+        assert used_small < used_big
+        g.clear()
+        assert scenes.run(g, big, "integrate").tobytes() == fresh["big"]  # grows past the bricks the smaller session reset
+        g.clear()
+        assert len(g.extract()) == 0 and g.counters()["bricks_allocated"] == 0
+
+
+def test_long_batches_take_the_larger_dry_run_vs_oracle(oracle_mod, hfpf_mod, synth_mod):
+    """A session's first batch of 64 frames or more is planned from a dry run of 16 frames instead of 8 (csrc/hfpf.hip
+    integrate_device_locked): two batches of 72 frames with a clean pass behind each, against the oracle."""
+    sc = scenes.Scene(144, 96, 72, 0.001, fx=92.25, clean_every=72)
+    og = oracle_mod.OracleGrid(resolution=sc.resolution, bbox=sc.bbox)
+    ref = scenes.run(og, sc, "capture")
+    with hfpf_mod.OccupancyGrid(resolution=sc.resolution, bbox=sc.bbox, **SMALL) as g:
+        fb = sc.W * sc.H * 16
+        dev = g.device_alloc(sc.n_frames * fb)
+        for f in range(sc.n_frames):
+            g.device_upload(dev + f * fb, sc.frame(f))
+        for e in range(2):
+            g.integrate_device(dev + e * 72 * fb, 72, fb, sc.W * sc.H, np.stack(sc.poses[e * 72:(e + 1) * 72]))
+            g.clean()
+        got = g.extract()
+        ctr = g.counters()
+        g.device_free(dev)
+    og.close()
+    assert ctr["dep_pairs_tested"] > 0
+    scenes.compare_rows(ref, got)
+
+
 def test_batched_device_frames_equal_single_host_frames(hfpf_mod, synth_mod):
     """hfpf_integrate_device with several frames per launch == one hfpf_integrate per frame (order-free sums)."""
     sc = scenes.Scene(6, 160, 120, 0.001, fx=615.0)
